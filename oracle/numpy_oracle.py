@@ -1,0 +1,260 @@
+"""Second, independent restatement of the reference filters on numpy.linalg (LAPACK).
+
+TEST INFRASTRUCTURE ONLY. PARITY UNPINNED (see kfpos_oracle.h). Its job is to cross-check
+the C++ oracle: same algorithm, different author-time, and LAPACK's inv/pinv/solve in place
+of the hand-written LU / Jacobi-SVD, which is also what Armadillo delegates to. One tag per
+object, pure-Python loops: small cases only.
+
+Reference map: MLLocation.cpp:24-37,153-278; KalmanFilterTOA.cpp:70-156,185-338,362-391,438-473;
+KalmanFilterTOAIMU.cpp:100-195,242-340,392-473 (with the 3-token repair of SURVEY.md 0.2).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+EPS = np.finfo(np.float64).eps
+
+
+class LinAlgThrow(Exception):
+    """Stands for the std::runtime_error Armadillo throws from inv / pinv / solve."""
+
+
+def _stdmax(a, b):
+    return b if a < b else a
+
+
+def arma_inv(A):
+    if A.size == 0:
+        return A.copy()
+    if not np.all(np.isfinite(A)):
+        raise LinAlgThrow("inv")
+    try:
+        return np.linalg.inv(A)
+    except np.linalg.LinAlgError as e:
+        raise LinAlgThrow("inv") from e
+
+
+def arma_pinv(A):
+    if A.size == 0:
+        return A.copy()
+    if not np.all(np.isfinite(A)):
+        raise LinAlgThrow("pinv")
+    U, s, Vt = np.linalg.svd(A)
+    tol = max(A.shape) * s[0] * EPS
+    keep = s > tol
+    return (Vt[keep].T / s[keep]) @ U[:, keep].T
+
+
+def arma_solve_equilibrate(A, b):
+    if not (np.all(np.isfinite(A)) and np.all(np.isfinite(b))):
+        raise LinAlgThrow("solve")
+    if np.linalg.cond(A, 1) * EPS > 1.0:
+        return arma_pinv(A) @ b
+    try:
+        return np.linalg.solve(A, b)
+    except np.linalg.LinAlgError:
+        return arma_pinv(A) @ b
+
+
+def distances(p, meas):
+    return [np.sqrt((bx - p[0]) * (bx - p[0]) + (by - p[1]) * (by - p[1]) + (bz - p[2]) * (bz - p[2]))
+            for (_, _, bx, by, bz) in meas]
+
+
+def ml_error(meas, p):
+    if not meas:
+        return -1.0
+    d = distances(p, meas)
+    return float(sum((d[i] - meas[i][0]) ** 2 for i in range(len(meas))))
+
+
+def ml_estimate(meas, seed):
+    """meas: list of (range, errEst, bx, by, bz). Returns (pos, cov or None, iters)."""
+    p = np.array(seed, dtype=np.float64)
+    n = len(meas)
+    if n < 4:
+        return p, None, 0
+    cost, new_cost, it = 1e20, 1.0, 0
+    with np.errstate(all="ignore"):
+        while abs(cost - new_cost) / cost > 1e-3 and it < 10000:
+            it += 1
+            cost = new_cost
+            d = distances(p, meas)
+            g, Hs = np.zeros(3), np.zeros((3, 3))
+            for i, (r, e, bx, by, bz) in enumerate(meas):
+                v = np.array([bx - p[0], by - p[1], bz - p[2]])
+                g += (r - d[i]) * v / (d[i] * e)
+                d3 = d[i] ** 3
+                for k in range(3):
+                    Hs[k, k] += (1 - r / d[i] + r * v[k] * v[k] / d3) / e
+                for (k, l) in ((0, 1), (0, 2), (1, 2)):
+                    t = r * v[k] * v[l] / (d3 * e)
+                    Hs[k, l] += t
+                    Hs[l, k] += t
+            p = arma_solve_equilibrate(Hs, Hs @ p - g)
+            d = distances(p, meas)
+            new_cost = sum((meas[i][0] - d[i]) ** 2 / meas[i][1] for i in range(n))
+        d = distances(p, meas)
+        rng_err = ml_error(meas, p)
+        J = np.array([[(p[0] - m[2]) / d[i], (p[1] - m[3]) / d[i], (p[2] - m[4]) / d[i]]
+                      for i, m in enumerate(meas)])
+        obs = np.array([_stdmax(m[1], rng_err) for m in meas])
+        C = arma_inv(J.T @ arma_inv(np.diag(obs)) @ J)
+    return p, C, it
+
+
+def pred_F(n, t):
+    F = np.eye(n)
+    for k in range(3):
+        F[k, k + 3] = t
+        if n == 9:
+            F[k, k + 6] = t * t / 2
+            F[k + 3, k + 6] = t
+    return F
+
+
+def pred_Q(n, t, accel_noise, jolt):
+    Q = np.zeros((n, n))
+    if n == 6:
+        t2, a2 = t ** 2 / 2, accel_noise * accel_noise
+        for k in range(3):
+            Q[k, k] = a2 * t2 * t2
+            Q[k, k + 3] = Q[k + 3, k] = a2 * t2 * t
+            Q[k + 3, k + 3] = a2 * t * t
+    else:
+        u = [t ** 3 / 6, t ** 2 / 2, t]
+        for k in range(3):
+            for a in range(3):
+                for b in range(3):
+                    Q[k + 3 * a, k + 3 * b] = jolt * u[min(a, b)] * u[max(a, b)]
+    return Q
+
+
+def iekf_step(n, pred, Pm, has_ranging, meas_all, ignored, has_imu, imu_acc, imu_cov, max_steps, tol):
+    """Shared body of kalmanStep3DIgnoreAnchor / kalmanStep3D. Returns (state, P, cost, gain_iters)."""
+    rm = [m for i, m in enumerate(meas_all) if i != ignored] if has_ranging else []
+    x = np.array(pred, dtype=np.float64)
+    nr = len(rm)
+    m = nr + (3 if has_imu else 0)
+    R, z = np.eye(m), np.zeros(m)
+    with np.errstate(all="ignore"):
+        if has_ranging:
+            ml, _, _ = ml_estimate(rm, x[:3])
+            if n == 6 and np.any(np.isnan(ml)):
+                ml = x[:3].copy()
+            e_ml = ml_error(rm, ml)
+            for i, mm in enumerate(rm):
+                z[i] = mm[0]
+                R[i, i] = _stdmax(e_ml, mm[1])
+        if has_imu:
+            z[nr:] = imu_acc
+            R[nr:, nr:] = np.asarray(imu_cov).reshape(3, 3)
+        Ri, Pp = arma_inv(R), arma_pinv(Pm)
+        H, K = np.zeros((m, n)), np.zeros((n, m))
+        cost, gains = 1e20, 0
+        for _ in range(max_steps):
+            h = np.zeros(m)
+            d = distances(x[:3], rm)
+            h[:nr] = d
+            if has_imu:
+                h[nr:] = x[6:9]
+            y, dl = z - h, pred - x
+            new_cost = float(y @ Ri @ y + dl @ Pp @ dl)
+            if abs(cost - new_cost) / cost < tol:
+                break
+            cost = new_cost
+            H[:] = 0.0
+            for i, mm in enumerate(rm):
+                H[i, 0:3] = [(x[0] - mm[2]) / d[i], (x[1] - mm[3]) / d[i], (x[2] - mm[4]) / d[i]]
+            if has_imu:
+                for k in range(3):
+                    H[nr + k, 6 + k] = x[6 + k]
+            K = Pm @ H.T @ arma_inv(H @ Pm @ H.T + R)
+            x = x + (dl + K @ (y - H @ dl))
+            gains += 1
+        Pn = (np.eye(n) - K @ H) @ Pm
+    return x, Pn, cost, gains
+
+
+class NumpyFilter:
+    """One reference filter; dt is passed in instead of read from the wall clock."""
+
+    def __init__(self, model, anchors, accel_noise=0.5, jolt=0.5, ignore_worst=False,
+                 cost_threshold=0.5, init_pos=None):
+        self.n = 9 if model == 1 else 6
+        self.anchors = np.asarray(anchors, dtype=np.float64)
+        self.accel_noise, self.jolt = accel_noise, jolt
+        self.ignore_worst, self.cost_threshold = ignore_worst, cost_threshold
+        self.fixed = init_pos is not None
+        self.pos = np.array(init_pos, dtype=np.float64) if self.fixed else np.full(3, np.nan)
+        self.vel = np.zeros(3)
+        self.P = np.zeros((self.n, self.n))
+        self.imu = None
+
+    def _meas(self, range_mm, err_est):
+        return [(float(mm) / 1000, float(e), *self.anchors[a]) for a, (mm, e) in
+                enumerate(zip(range_mm, err_est)) if mm > 0]
+
+    def step_toa(self, range_mm, err_est, dt):
+        meas = self._meas(range_mm, err_est)
+        if self.n == 6:
+            return self._toa6(meas, dt)
+        return self._imu9(True, meas, self.imu is not None, dt)
+
+    def step_imu(self, accel, cov, dt):
+        if self.n == 9:
+            self.imu = (np.array(accel, dtype=np.float64), np.array(cov, dtype=np.float64))
+            self._imu9(False, [], True, dt)
+
+    def _toa6(self, meas, dt):
+        if not self.fixed and np.any(np.isnan(self.pos)):
+            if len(meas) < 4:
+                return
+            p, C, _ = ml_estimate(meas, [1.0, 1.0, 4.0])
+            self.pos = p
+            for i in range(3):
+                self.P[i, 0], self.P[i, 1], self.P[i, 2] = C[i, 0], C[i, 1], C[i, 1]
+            return
+        F, Q = pred_F(6, dt), pred_Q(6, dt, self.accel_noise, self.jolt)
+        pred = F @ np.concatenate([self.pos, np.zeros(3)])
+        self.P = F @ self.P @ F.T + Q
+        try:
+            if len(meas) > 4 and self.ignore_worst:
+                x_all, P_all, c_all, _ = iekf_step(6, pred, self.P, True, meas, -1, False, None, None, 10, 1e-3)
+                best, max_d, worst_cost = None, 0.0, 0.0
+                for i, mm in enumerate(meas):
+                    xi, Pi, ci, _ = iekf_step(6, pred, self.P, True, meas, i, False, None, None, 10, 1e-3)
+                    dd = mm[0] - np.sqrt((mm[2] - xi[0]) ** 2 + (mm[3] - xi[1]) ** 2 + (mm[4] - xi[2]) ** 2)
+                    if i == 0 or dd > max_d:
+                        max_d, worst_cost, best = dd, ci, (xi, Pi)
+                x, Pn = x_all, P_all
+                if max_d > 0 and (c_all - worst_cost) > self.cost_threshold:
+                    x, Pn = best
+            else:
+                x, Pn, _, _ = iekf_step(6, pred, self.P, True, meas, -1, False, None, None, 10, 1e-3)
+        except LinAlgThrow:
+            return
+        self.P, self.pos = Pn, x[:3].copy()
+
+    def _imu9(self, has_ranging, meas, has_imu, dt):
+        if not self.fixed and (np.isnan(self.pos[0]) or np.isnan(self.pos[1])):
+            if has_ranging and len(meas) >= 4:
+                p, C, _ = ml_estimate(meas, [1.0, 1.0, 4.0])
+                self.pos = p
+                self.P[0, 0], self.P[1, 0], self.P[0, 1], self.P[1, 1] = C[0, 0], C[1, 0], C[0, 1], C[1, 1]
+            return
+        F, Q = pred_F(9, dt), pred_Q(9, dt, self.accel_noise, self.jolt)
+        pred = F @ np.concatenate([self.pos, self.vel, np.zeros(3)])
+        self.P = F @ self.P @ F.T + Q
+        acc, cov = self.imu if has_imu else (None, None)
+        try:
+            x, Pn, _, _ = iekf_step(9, pred, self.P, has_ranging, meas, -1, has_imu, acc, cov, 20, 1e-4)
+        except LinAlgThrow:
+            return
+        self.P, self.pos, self.vel = Pn, x[:3].copy(), x[3:6].copy()
+
+    def get_pose(self, dt_ahead):
+        F, Q = pred_F(self.n, dt_ahead), pred_Q(self.n, dt_ahead, self.accel_noise, self.jolt)
+        st = np.concatenate([self.pos, self.vel if self.n == 9 else np.zeros(3), np.zeros(self.n - 6)])
+        Pp = F @ self.P @ F.T + Q
+        return (F @ st)[:3], Pp[:3, :3]

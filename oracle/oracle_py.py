@@ -1,0 +1,162 @@
+"""ctypes binding of the CPU oracle (oracle/libkfpos_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg, never by the product package. PARITY UNPINNED (see kfpos_oracle.h).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_DIR, "libkfpos_oracle.so")
+
+MODEL_TOA, MODEL_TOA_IMU = 0, 1
+ST_UPDATE_SKIPPED, ST_ML_FALLBACK, ST_FEW_RANGES, ST_ML_INIT, ST_NOT_STARTED, ST_NONFINITE = 1, 2, 4, 8, 16, 32
+
+_dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+_up = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_DIR, "kfpos_oracle.cpp")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _DIR, "-B" if force else "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = C.CDLL(_SO)
+        L.kfo_create.restype = C.c_void_p
+        L.kfo_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_double,
+                                 C.c_int, C.c_int, C.c_void_p]
+        L.kfo_destroy.argtypes = [C.c_void_p]
+        L.kfo_state_dim.argtypes = [C.c_void_p]
+        L.kfo_set_anchors.argtypes = [C.c_void_p, _dp, C.c_int]
+        L.kfo_step_toa.argtypes = [C.c_void_p, _ip, _dp, _dp, C.c_int, C.c_void_p, C.c_int]
+        L.kfo_step_imu.argtypes = [C.c_void_p, _dp, _dp, _dp, C.c_int, C.c_void_p, C.c_int]
+        L.kfo_get_pose.argtypes = [C.c_void_p, C.c_double, _dp, _dp, C.c_void_p, C.c_void_p]
+        L.kfo_get_state.argtypes = [C.c_void_p, _dp, _dp]
+        L.kfo_set_state.argtypes = [C.c_void_p, _dp, _dp, C.c_int]
+        L.kfo_ml_estimate.argtypes = [C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_void_p]
+        L.kfo_predict_matrices.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, _dp, _dp]
+        L.kfo_inv.argtypes = [C.c_int, _dp, _dp]
+        L.kfo_pinv.argtypes = [C.c_int, _dp, _dp]
+        L.kfo_solve_equilibrate.argtypes = [C.c_int, _dp, _dp, _dp]
+        L.kfo_topn_keep.argtypes = [C.c_int, _dp, _dp, _dp, _dp, C.c_int, _ip]
+        _lib = L
+    return _lib
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class OracleBank:
+    """T independent reference filters (KalmanFilterTOA or repaired KalmanFilterTOAIMU)."""
+
+    def __init__(self, model, n_tags, anchors, accel_noise=0.5, jolt=0.5, ignore_worst=False,
+                 cost_threshold=0.5, top_n=0, init_pos=None, n_threads=1):
+        self.model, self.T = model, n_tags
+        self.anchors = _f64(anchors)
+        self.A = self.anchors.shape[0]
+        self.n_threads = n_threads
+        ip = None
+        if init_pos is not None:
+            ip = _f64(init_pos)
+            assert ip.shape == (n_tags, 3)
+        self._h = lib().kfo_create(model, n_tags, self.A, accel_noise, jolt, int(ignore_worst),
+                                   cost_threshold, top_n, int(init_pos is not None),
+                                   ip.ctypes.data if ip is not None else None)
+        lib().kfo_set_anchors(self._h, self.anchors, self.A)
+        self.n = lib().kfo_state_dim(self._h)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().kfo_destroy(self._h)
+            self._h = None
+
+    def _dt(self, dt):
+        d = np.atleast_1d(_f64(dt))
+        assert d.size in (1, self.T)
+        return d
+
+    def step_toa(self, range_mm, err_est, dt):
+        r = np.ascontiguousarray(range_mm, dtype=np.int32)
+        e = _f64(err_est)
+        assert r.shape == (self.T, self.A) and e.shape == (self.T, self.A)
+        d = self._dt(dt)
+        st = np.zeros(self.T, dtype=np.uint32)
+        lib().kfo_step_toa(self._h, r, e, d, d.size, st.ctypes.data, self.n_threads)
+        return st
+
+    def step_imu(self, accel, cov, dt):
+        a, c = _f64(accel), _f64(cov)
+        assert a.shape == (self.T, 3) and c.shape == (self.T, 9)
+        d = self._dt(dt)
+        st = np.zeros(self.T, dtype=np.uint32)
+        lib().kfo_step_imu(self._h, a, c, d, d.size, st.ctypes.data, self.n_threads)
+        return st
+
+    def get_pose(self, dt_ahead=0.0):
+        pos, cov, vel = np.zeros((self.T, 3)), np.zeros((self.T, 9)), np.zeros((self.T, 3))
+        st = np.zeros(self.T, dtype=np.uint32)
+        lib().kfo_get_pose(self._h, dt_ahead, pos, cov, vel.ctypes.data, st.ctypes.data)
+        return pos, cov.reshape(self.T, 3, 3), vel, st
+
+    def get_state(self):
+        x, P = np.zeros((self.T, self.n)), np.zeros((self.T, self.n, self.n))
+        lib().kfo_get_state(self._h, x, P)
+        return x, P
+
+    def set_state(self, x, P, started=True):
+        lib().kfo_set_state(self._h, _f64(x), _f64(P), int(started))
+
+
+def ml_estimate(anchors, ranges, err_est, seed):
+    a, r, e, s = _f64(anchors), _f64(ranges), _f64(err_est), _f64(seed)
+    pos, cov = np.zeros(3), np.zeros(9)
+    it = lib().kfo_ml_estimate(len(r), a, r, e, s, pos, cov.ctypes.data)
+    return pos, cov.reshape(3, 3), it
+
+
+def predict_matrices(model, dt, accel_noise=0.5, jolt=0.5):
+    n = 9 if model == MODEL_TOA_IMU else 6
+    F, Q = np.zeros((n, n)), np.zeros((n, n))
+    lib().kfo_predict_matrices(model, dt, accel_noise, jolt, F, Q)
+    return F, Q
+
+
+def inv(A):
+    A = _f64(A)
+    out = np.zeros_like(A)
+    return out, lib().kfo_inv(A.shape[0], A, out)
+
+
+def pinv(A):
+    A = _f64(A)
+    out = np.zeros_like(A)
+    return out, lib().kfo_pinv(A.shape[0], A, out)
+
+
+def solve_equilibrate(A, b):
+    A, b = _f64(A), _f64(b)
+    x = np.zeros_like(b)
+    return x, lib().kfo_solve_equilibrate(A.shape[0], A, b, x)
+
+
+def topn_keep(anchors, ranges, err_est, seed, top_n):
+    keep = np.zeros(len(ranges), dtype=np.int32)
+    lib().kfo_topn_keep(len(ranges), _f64(anchors), _f64(ranges), _f64(err_est), _f64(seed), top_n, keep)
+    return keep
