@@ -1,0 +1,185 @@
+/*
+ * kfpos.h -- C ABI of the MI355X batched EKF positioning core (libkfpos_hip.so).
+ *
+ * Drop-in boundary: the reference's estimator interface
+ *   class PositionEstimationAlgorithm   src/kfpos/algorithms/PositionEstimationAlgorithm.h:8-37
+ * as implemented by
+ *   KalmanFilterTOA      src/kfpos/algorithms/KalmanFilterTOA.{h,cpp}     (ALGORITHM_KF_TOA)
+ *   KalmanFilterTOAIMU   src/kfpos/algorithms/KalmanFilterTOAIMU.{h,cpp}  (ALGORITHM_KF_TOA_IMU)
+ * and called from PosGenerator (src/kfpos/publishers/Posgenerator.cpp:491 newTOAMeasurement,
+ * :139 newIMUMeasurement, :537 init, :543 getPose). The reference runs ONE filter for ONE tag per
+ * process; this library runs T independent filters per handle, one per GPU lane, with the same
+ * per-filter semantics. The wall clock the reference reads inside the estimator
+ * (KalmanFilterTOA.cpp:76-88) is passed in as dt. Plain C types only: no exceptions cross this
+ * boundary, per-tag conditions are reported in a status word instead.
+ *
+ * Host-side mirrors of the reference classes on top of this ABI: roskfpos_amd/csrc/kfpos_adaptor.h.
+ * The binding a reference maintainer would add: INTEGRATION.md.
+ */
+#ifndef KFPOS_H
+#define KFPOS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KFPOS_VERSION 100 /* 0.1.0 */
+
+/* ---- return codes (every entry point returns one; 0 = success) ---- */
+#define KFPOS_OK            0
+#define KFPOS_ERR_ARG       1 /* NULL / out-of-range argument */
+#define KFPOS_ERR_HIP       2 /* a HIP call failed; kfpos_last_error() has the text */
+#define KFPOS_ERR_NO_DEVICE 3 /* no usable gfx950 device */
+#define KFPOS_ERR_MODEL     4 /* call not defined for this handle's model */
+#define KFPOS_ERR_STATE     5 /* e.g. anchors not set yet (Posgenerator.cpp:92-96 drops ranges until then) */
+
+/* ---- models: the `algorithm` launch parameter (node_pos.cpp:48-58) ---- */
+#define KFPOS_MODEL_TOA     0 /* ALGORITHM_KF_TOA     -> KalmanFilterTOA, 6 states p,v */
+#define KFPOS_MODEL_TOA_IMU 1 /* ALGORITHM_KF_TOA_IMU -> KalmanFilterTOAIMU, 9 states p,v,a (3-token repair) */
+
+/* ---- storage precision of covariance / velocity / measurements in HBM; arithmetic is always f64 ---- */
+#define KFPOS_STORE_F64 0 /* kfpos_real = double */
+#define KFPOS_STORE_F32 1 /* kfpos_real = float (positions stay double; ranges are exact integer mm) */
+
+#define KFPOS_MAX_ANCHORS 64 /* MAX_NUM_ANCS, Posgenerator.h:74 */
+
+/* ---- per-tag status word ---- */
+#define KFPOS_ST_UPDATE_SKIPPED 0x01u /* the std::runtime_error the reference swallows (KalmanFilterTOA.cpp:151-153) */
+#define KFPOS_ST_ML_FALLBACK    0x02u /* ML position NaN -> predicted position (KalmanFilterTOA.cpp:270-272) */
+#define KFPOS_ST_FEW_RANGES     0x04u /* < 4 ranges this epoch: ML returned its seed (MLLocation.cpp:158-161) */
+#define KFPOS_ST_ML_INIT        0x08u /* this epoch was consumed by the ML initialisation (KalmanFilterTOA.cpp:90-108) */
+#define KFPOS_ST_NOT_STARTED    0x10u /* getPose() == false: no measurement yet (KalmanFilterTOA.cpp:442-447) */
+#define KFPOS_ST_NONFINITE      0x20u /* state not finite after the call */
+#define KFPOS_ST_GAIN_ITERS(s)  (((s) >> 8) & 0xffu)  /* IEKF gain iterations (KalmanFilterTOA.cpp:293-324) */
+#define KFPOS_ST_ML_ITERS(s)    (((s) >> 16) & 0xffu) /* ML Gauss-Newton iterations, saturating (MLLocation.cpp:168-225) */
+#define KFPOS_ST_IGNORED(s)     ((int)(((s) >> 24) & 0xffu) - 1) /* index among this epoch's >0 ranges of the anchor the
+                                                                    leave-one-out heuristic dropped, -1 if none */
+
+/* Construction parameters: the constructor arguments of KalmanFilterTOA (KalmanFilterTOA.h:21-22) and
+ * KalmanFilterTOAIMU (KalmanFilterTOAIMU.h:19-20) plus the batch shape. Launch-file names in brackets. */
+typedef struct kfpos_config {
+    int32_t model;          /* KFPOS_MODEL_*                                   [algorithm] */
+    int32_t n_tags;         /* T, filters in this handle (>= 1) */
+    int32_t max_anchors;    /* A, columns of the range matrix, 1..KFPOS_MAX_ANCHORS */
+    int32_t storage;        /* KFPOS_STORE_* */
+    double  accel_noise;    /* accelerationNoise                               [accelNoise], kfpos_toa.launch:13 */
+    double  jolt;           /* jolt (9-state process noise)                    [jolt], kfpos_toa_imu.launch */
+    int32_t ignore_worst;   /* ignoreWorstAnchorMode (6-state only)            [useHeuristicIgnoreWorst] */
+    double  cost_threshold; /* ignoreCostThreshold                             [heuristicIgnoreThreshold] */
+    int32_t top_n;          /* ranges dropped by residual ranking, 0 = off     [numRangingsToIgnore], BASELINE config 5 */
+    int32_t use_init_pos;   /* 1: fixed initial position, P0 = 0; 0: ML initialisation on the first epoch
+                               (the reference's mUseFixedInitialPosition)      [useStartPosition] */
+    double  init_pos[3];    /* initialPosition for every tag                   [initPositionX/Y/Z]; per-tag values:
+                               kfpos_set_init_positions() */
+    int32_t device;         /* HIP device ordinal */
+} kfpos_config;
+
+typedef struct kfpos_handle kfpos_handle;
+
+/* ---- lifetime: PosGenerator::setAlgorithm (Posgenerator.cpp:510-538) ---- */
+int kfpos_create(const kfpos_config *cfg, kfpos_handle **out);
+int kfpos_destroy(kfpos_handle *h);
+/* PositionEstimationAlgorithm::init(). Returns KFPOS_OK (the reference's `true`). */
+int kfpos_init(kfpos_handle *h);
+/* Beacon table: what PosGenerator keeps in `beacons` from the anchors topic (Posgenerator.cpp:15-39)
+ * and zips into newTOAMeasurement's `beacons` argument (:486-487). xyz: n_anchors*3 doubles, metres.
+ * ids may be NULL (kept for the caller's id->column map only). */
+int kfpos_set_anchors(kfpos_handle *h, const double *xyz, const int32_t *ids, int32_t n_anchors);
+/* Per-tag fixed start positions, n_tags*3 doubles (batched form of the initialPosition ctor argument).
+ * Only before the first step and only with use_init_pos = 1. */
+int kfpos_set_init_positions(kfpos_handle *h, const double *xyz);
+
+/* size in bytes of kfpos_real for this handle (8 or 4) */
+int kfpos_real_size(const kfpos_handle *h);
+
+/* ---- synchronous host-buffer API (pointers are borrowed until the call returns) ---- */
+
+/* One ranging epoch for every tag = T calls of newTOAMeasurement (KalmanFilterTOA.cpp:43-61,
+ * KalmanFilterTOAIMU.cpp:49-73) -> estimatePositionKF (predict + iterated update).
+ *   range_mm  n_tags x max_anchors, row-major, integer millimetres exactly as PosGenerator stores them
+ *             (Posgenerator.cpp:213); <= 0 = no range from that anchor this epoch (:483)
+ *   err_est   n_tags x max_anchors, kfpos_real, m^2, must be > 0 where a range is present (:485)
+ *   dt        seconds since the previous estimate of each tag (the reference's wall-clock timeLag;
+ *             0.1 on a filter's first call, KalmanFilterTOA.cpp:81); dt_len = 1 (shared) or n_tags
+ *   status    n_tags words or NULL
+ * A 9-state handle fuses the latched IMU sample again, as the reference does (KalmanFilterTOAIMU.cpp:68-72). */
+int kfpos_step_toa(kfpos_handle *h, const int32_t *range_mm, const void *err_est,
+                   const double *dt, int32_t dt_len, uint32_t *status);
+
+/* One IMU sample for every tag = T calls of newIMUMeasurement (KalmanFilterTOAIMU.cpp:76-92): latch
+ * linearAcceleration + covarianceAcceleration, then predict + IMU-only update. angularVelocity and its
+ * covariance are ignored by the reference and are not part of this ABI. 6-state handles: no-op
+ * (KalmanFilterTOA.cpp:64), returns KFPOS_OK.
+ *   accel n_tags x 3, cov n_tags x 9 (row-major 3x3, symmetric positive definite), kfpos_real */
+int kfpos_step_imu(kfpos_handle *h, const void *accel, const void *cov,
+                   const double *dt, int32_t dt_len, uint32_t *status);
+
+/* Fused epoch: latch the IMU sample, then the ranging epoch -- exactly the reference sequence
+ * { newIMUMeasurement at timeLag 0 ; newTOAMeasurement at timeLag dt } (the IMU-only estimate is the
+ * identity at timeLag 0). 9-state handles only. */
+int kfpos_step_toa_imu(kfpos_handle *h, const int32_t *range_mm, const void *err_est,
+                       const void *accel, const void *cov,
+                       const double *dt, int32_t dt_len, uint32_t *status);
+
+/* getPose for every tag (KalmanFilterTOA.cpp:438-473, KalmanFilterTOAIMU.cpp:476-510): predict-only
+ * extrapolation by dt_ahead, filter state untouched. pos n_tags x 3, cov3x3 n_tags x 9 (position block of
+ * the predicted covariance; the only block stateToPose fills, KalmanFilterTOA.cpp:159-183), vel n_tags x 3
+ * (linearSpeed*, 9-state; zeros for 6-state), all double; any may be NULL. A tag without a measurement
+ * yet reports KFPOS_ST_NOT_STARTED and NaN (getPose() == false). */
+int kfpos_get_pose(kfpos_handle *h, double dt_ahead, double *pos, double *cov3x3, double *vel,
+                   uint32_t *status);
+
+/* Raw filter members for tests and checkpoint/restore: x n_tags x n ([p, v(, a = 0)]),
+ * P n_tags x n x n row-major, double. n = kfpos_state_dim(). flags: n_tags words (bit 0 started,
+ * bit 1 has latched IMU), may be NULL. */
+int kfpos_state_dim(const kfpos_handle *h);
+int kfpos_get_state(kfpos_handle *h, double *x, double *P, uint32_t *flags);
+int kfpos_set_state(kfpos_handle *h, const double *x, const double *P, const uint32_t *flags);
+
+/* ---- asynchronous device-buffer API (inputs already resident in HBM) ----
+ * All pointers are device pointers; `stream` is a hipStream_t (NULL = the default stream). Calls
+ * enqueue work and return; the caller synchronises. Device layouts are component-major so that the
+ * 64 lanes of a wavefront read 64 consecutive elements:
+ *   range_mm [max_anchors][n_tags] int32      err_est [max_anchors][n_tags] kfpos_real
+ *   accel    [3][n_tags] kfpos_real           cov     [9][n_tags] kfpos_real (row-major 3x3 index first)
+ *   dt       [n_tags] double, or NULL to use the shared dt_shared
+ *   status   [n_tags] uint32 or NULL
+ *   pos      [3][n_tags] double               cov3x3  [9][n_tags] double      vel [3][n_tags] double */
+int kfpos_step_toa_dev(kfpos_handle *h, const int32_t *range_mm, const void *err_est,
+                       const double *dt, double dt_shared, uint32_t *status, void *stream);
+int kfpos_step_imu_dev(kfpos_handle *h, const void *accel, const void *cov,
+                       const double *dt, double dt_shared, uint32_t *status, void *stream);
+/* latch != 0 also stores the sample in the handle (needed if a later kfpos_step_toa* call is to
+ * re-fuse it); latch = 0 skips that write when every epoch brings its own sample. */
+int kfpos_step_toa_imu_dev(kfpos_handle *h, const int32_t *range_mm, const void *err_est,
+                           const void *accel, const void *cov, int32_t latch,
+                           const double *dt, double dt_shared, uint32_t *status, void *stream);
+int kfpos_get_pose_dev(kfpos_handle *h, double dt_ahead, double *pos, double *cov3x3, double *vel,
+                       uint32_t *status, void *stream);
+
+/* Replay a whole trace resident in HBM: n_steps epochs, epoch s reading range_mm + s*step_stride_ranges
+ * elements etc. (strides in elements; err_est/cov strides may be 0 to reuse one array). Equivalent to
+ * n_steps calls of kfpos_step_toa_dev / kfpos_step_toa_imu_dev (accel != NULL) with dt_steps[s] shared by
+ * all tags (host array). Launches are enqueued back to back on `stream`. */
+int kfpos_run_trace_dev(kfpos_handle *h, int32_t n_steps,
+                        const int32_t *range_mm, int64_t stride_ranges,
+                        const void *err_est, int64_t stride_err,
+                        const void *accel, int64_t stride_accel,
+                        const void *cov, int64_t stride_cov,
+                        const double *dt_steps, uint32_t *status, void *stream);
+
+/* ---- diagnostics ---- */
+const char *kfpos_last_error(void);  /* thread-local text of the last KFPOS_ERR_HIP */
+const char *kfpos_strerror(int code);
+int kfpos_version(void);
+/* name / duration helpers for benchmarks: time the last n enqueued step kernels with HIP events on the
+ * stream they were launched on. kfpos_timing_begin records, kfpos_timing_end synchronises and returns ms. */
+int kfpos_timing_begin(kfpos_handle *h, void *stream);
+int kfpos_timing_end(kfpos_handle *h, void *stream, float *elapsed_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KFPOS_H */

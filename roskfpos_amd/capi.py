@@ -1,0 +1,235 @@
+"""ctypes binding of libkfpos_hip.so (include/kfpos.h) -- the only compute path of this package.
+
+There is no CPU fallback: importing works anywhere, but creating a bank raises if the HIP
+library has not been built (`python -c "import __graft_entry__ as g; g.build()"`) or no GPU
+is present. Mirrors the reference's estimator interface batched over T tags:
+PositionEstimationAlgorithm (src/kfpos/algorithms/PositionEstimationAlgorithm.h:8-37).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_DIR, "csrc", "libkfpos_hip.so")
+
+MODEL_TOA, MODEL_TOA_IMU = 0, 1
+STORE_F64, STORE_F32 = 0, 1
+MAX_ANCHORS = 64
+ST_UPDATE_SKIPPED, ST_ML_FALLBACK, ST_FEW_RANGES, ST_ML_INIT, ST_NOT_STARTED, ST_NONFINITE = 1, 2, 4, 8, 16, 32
+
+# every symbol include/kfpos.h declares
+EXPORTS = [
+    "kfpos_create", "kfpos_destroy", "kfpos_init", "kfpos_set_anchors", "kfpos_set_init_positions",
+    "kfpos_real_size", "kfpos_step_toa", "kfpos_step_imu", "kfpos_step_toa_imu", "kfpos_get_pose",
+    "kfpos_state_dim", "kfpos_get_state", "kfpos_set_state", "kfpos_step_toa_dev", "kfpos_step_imu_dev",
+    "kfpos_step_toa_imu_dev", "kfpos_get_pose_dev", "kfpos_run_trace_dev", "kfpos_last_error",
+    "kfpos_strerror", "kfpos_version", "kfpos_timing_begin", "kfpos_timing_end",
+]
+
+
+class KfposError(RuntimeError):
+    pass
+
+
+class _Config(C.Structure):
+    _fields_ = [("model", C.c_int32), ("n_tags", C.c_int32), ("max_anchors", C.c_int32),
+                ("storage", C.c_int32), ("accel_noise", C.c_double), ("jolt", C.c_double),
+                ("ignore_worst", C.c_int32), ("cost_threshold", C.c_double), ("top_n", C.c_int32),
+                ("use_init_pos", C.c_int32), ("init_pos", C.c_double * 3), ("device", C.c_int32)]
+
+
+_lib = None
+
+
+def load():
+    """Load the HIP library; raises KfposError (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise KfposError(f"{LIB_PATH} is not built: run __graft_entry__.build() (hipcc --offload-arch=gfx950)")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, f64 = C.c_void_p, C.c_int32, C.c_double
+    L.kfpos_create.argtypes = [C.POINTER(_Config), C.POINTER(vp)]
+    L.kfpos_destroy.argtypes = [vp]
+    L.kfpos_init.argtypes = [vp]
+    L.kfpos_set_anchors.argtypes = [vp, vp, vp, i32]
+    L.kfpos_set_init_positions.argtypes = [vp, vp]
+    L.kfpos_real_size.argtypes = [vp]
+    L.kfpos_state_dim.argtypes = [vp]
+    L.kfpos_step_toa.argtypes = [vp, vp, vp, vp, i32, vp]
+    L.kfpos_step_imu.argtypes = [vp, vp, vp, vp, i32, vp]
+    L.kfpos_step_toa_imu.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp]
+    L.kfpos_get_pose.argtypes = [vp, f64, vp, vp, vp, vp]
+    L.kfpos_get_state.argtypes = [vp, vp, vp, vp]
+    L.kfpos_set_state.argtypes = [vp, vp, vp, vp]
+    L.kfpos_step_toa_dev.argtypes = [vp, vp, vp, vp, f64, vp, vp]
+    L.kfpos_step_imu_dev.argtypes = [vp, vp, vp, vp, f64, vp, vp]
+    L.kfpos_step_toa_imu_dev.argtypes = [vp, vp, vp, vp, vp, i32, vp, f64, vp, vp]
+    L.kfpos_get_pose_dev.argtypes = [vp, f64, vp, vp, vp, vp, vp]
+    L.kfpos_run_trace_dev.argtypes = [vp, i32, vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, vp, C.c_int64,
+                                      vp, vp, vp]
+    L.kfpos_timing_begin.argtypes = [vp, vp]
+    L.kfpos_timing_end.argtypes = [vp, vp, C.POINTER(C.c_float)]
+    L.kfpos_last_error.restype = C.c_char_p
+    L.kfpos_strerror.restype = C.c_char_p
+    L.kfpos_strerror.argtypes = [C.c_int]
+    _lib = L
+    return L
+
+
+def _ptr(x):
+    """device pointer from an int, None, or anything with data_ptr() (torch tensors)."""
+    if x is None:
+        return None
+    if hasattr(x, "data_ptr"):
+        return x.data_ptr()
+    return int(x)
+
+
+class KfposBank:
+    """T independent filters on one GPU (KalmanFilterTOA or KalmanFilterTOAIMU semantics per tag)."""
+
+    def __init__(self, model, n_tags, anchors, storage=STORE_F64, accel_noise=0.5, jolt=0.5,
+                 ignore_worst=False, cost_threshold=0.5, top_n=0, init_pos=None, device=0,
+                 max_anchors=None):
+        self._h = None
+        self.lib = load()
+        anchors = np.ascontiguousarray(anchors, dtype=np.float64)
+        self.T, self.A = int(n_tags), int(max_anchors or anchors.shape[0])
+        self.model, self.storage = model, storage
+        self.real = np.float32 if storage == STORE_F32 else np.float64
+        cfg = _Config()
+        cfg.model, cfg.n_tags, cfg.max_anchors, cfg.storage = model, self.T, self.A, storage
+        cfg.accel_noise, cfg.jolt = accel_noise, jolt
+        cfg.ignore_worst, cfg.cost_threshold, cfg.top_n = int(ignore_worst), cost_threshold, top_n
+        cfg.use_init_pos = int(init_pos is not None)
+        per_tag = None
+        if init_pos is not None:
+            ip = np.asarray(init_pos, dtype=np.float64)
+            if ip.shape == (3,):
+                cfg.init_pos = (C.c_double * 3)(*ip)
+            else:
+                assert ip.shape == (self.T, 3)
+                per_tag = np.ascontiguousarray(ip)
+        cfg.device = device
+        h = C.c_void_p()
+        self._chk(self.lib.kfpos_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+        self._chk(self.lib.kfpos_init(h))
+        self._chk(self.lib.kfpos_set_anchors(h, anchors.ctypes.data, None, anchors.shape[0]))
+        if per_tag is not None:
+            self._chk(self.lib.kfpos_set_init_positions(h, per_tag.ctypes.data))
+        self.n = self.lib.kfpos_state_dim(h)
+
+    def _chk(self, rc):
+        if rc != 0:
+            msg = self.lib.kfpos_strerror(rc).decode()
+            if rc == 2:
+                msg += ": " + self.lib.kfpos_last_error().decode()
+            raise KfposError(msg)
+
+    def close(self):
+        if self._h:
+            self.lib.kfpos_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- host-buffer API ------------------------------------------------------
+    def _dt(self, dt):
+        d = np.atleast_1d(np.ascontiguousarray(dt, dtype=np.float64))
+        assert d.size in (1, self.T)
+        return d
+
+    def step_toa(self, range_mm, err_est, dt):
+        r = np.ascontiguousarray(range_mm, dtype=np.int32)
+        e = np.ascontiguousarray(err_est, dtype=self.real)
+        assert r.shape == (self.T, self.A) and e.shape == (self.T, self.A)
+        d, st = self._dt(dt), np.zeros(self.T, dtype=np.uint32)
+        self._chk(self.lib.kfpos_step_toa(self._h, r.ctypes.data, e.ctypes.data, d.ctypes.data, d.size,
+                                          st.ctypes.data))
+        return st
+
+    def step_imu(self, accel, cov, dt):
+        a = np.ascontiguousarray(accel, dtype=self.real)
+        c = np.ascontiguousarray(cov, dtype=self.real)
+        assert a.shape == (self.T, 3) and c.shape == (self.T, 9)
+        d, st = self._dt(dt), np.zeros(self.T, dtype=np.uint32)
+        self._chk(self.lib.kfpos_step_imu(self._h, a.ctypes.data, c.ctypes.data, d.ctypes.data, d.size,
+                                          st.ctypes.data))
+        return st
+
+    def step_toa_imu(self, range_mm, err_est, accel, cov, dt):
+        r = np.ascontiguousarray(range_mm, dtype=np.int32)
+        e = np.ascontiguousarray(err_est, dtype=self.real)
+        a = np.ascontiguousarray(accel, dtype=self.real)
+        c = np.ascontiguousarray(cov, dtype=self.real)
+        assert r.shape == (self.T, self.A) and e.shape == (self.T, self.A)
+        assert a.shape == (self.T, 3) and c.shape == (self.T, 9)
+        d, st = self._dt(dt), np.zeros(self.T, dtype=np.uint32)
+        self._chk(self.lib.kfpos_step_toa_imu(self._h, r.ctypes.data, e.ctypes.data, a.ctypes.data,
+                                              c.ctypes.data, d.ctypes.data, d.size, st.ctypes.data))
+        return st
+
+    def get_pose(self, dt_ahead=0.0):
+        pos, cov, vel = np.zeros((self.T, 3)), np.zeros((self.T, 9)), np.zeros((self.T, 3))
+        st = np.zeros(self.T, dtype=np.uint32)
+        self._chk(self.lib.kfpos_get_pose(self._h, dt_ahead, pos.ctypes.data, cov.ctypes.data,
+                                          vel.ctypes.data, st.ctypes.data))
+        return pos, cov.reshape(self.T, 3, 3), vel, st
+
+    def get_state(self):
+        x, P = np.zeros((self.T, self.n)), np.zeros((self.T, self.n, self.n))
+        fl = np.zeros(self.T, dtype=np.uint32)
+        self._chk(self.lib.kfpos_get_state(self._h, x.ctypes.data, P.ctypes.data, fl.ctypes.data))
+        return x, P, fl
+
+    def set_state(self, x, P, flags=None):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        P = np.ascontiguousarray(P, dtype=np.float64)
+        fl = None if flags is None else np.ascontiguousarray(flags, dtype=np.uint32)
+        self._chk(self.lib.kfpos_set_state(self._h, x.ctypes.data, P.ctypes.data,
+                                           None if fl is None else fl.ctypes.data))
+
+    # ---- device-buffer API (pointers: ints or torch tensors; layouts in include/kfpos.h) ----
+    def step_toa_dev(self, range_mm, err_est, dt, status=None, stream=None, dt_dev=None):
+        self._chk(self.lib.kfpos_step_toa_dev(self._h, _ptr(range_mm), _ptr(err_est), _ptr(dt_dev), float(dt),
+                                              _ptr(status), _ptr(stream)))
+
+    def step_imu_dev(self, accel, cov, dt, status=None, stream=None, dt_dev=None):
+        self._chk(self.lib.kfpos_step_imu_dev(self._h, _ptr(accel), _ptr(cov), _ptr(dt_dev), float(dt),
+                                              _ptr(status), _ptr(stream)))
+
+    def step_toa_imu_dev(self, range_mm, err_est, accel, cov, dt, latch=True, status=None, stream=None,
+                         dt_dev=None):
+        self._chk(self.lib.kfpos_step_toa_imu_dev(self._h, _ptr(range_mm), _ptr(err_est), _ptr(accel),
+                                                  _ptr(cov), int(latch), _ptr(dt_dev), float(dt),
+                                                  _ptr(status), _ptr(stream)))
+
+    def get_pose_dev(self, dt_ahead, pos=None, cov=None, vel=None, status=None, stream=None):
+        self._chk(self.lib.kfpos_get_pose_dev(self._h, float(dt_ahead), _ptr(pos), _ptr(cov), _ptr(vel),
+                                              _ptr(status), _ptr(stream)))
+
+    def run_trace_dev(self, n_steps, range_mm, stride_ranges, err_est, stride_err, dt_steps, accel=None,
+                      stride_accel=0, cov=None, stride_cov=0, status=None, stream=None):
+        d = np.ascontiguousarray(dt_steps, dtype=np.float64)
+        assert d.size >= n_steps
+        self._chk(self.lib.kfpos_run_trace_dev(self._h, n_steps, _ptr(range_mm), stride_ranges, _ptr(err_est),
+                                               stride_err, _ptr(accel), stride_accel, _ptr(cov), stride_cov,
+                                               d.ctypes.data, _ptr(status), _ptr(stream)))
+
+    def timing_begin(self, stream=None):
+        self._chk(self.lib.kfpos_timing_begin(self._h, _ptr(stream)))
+
+    def timing_end(self, stream=None) -> float:
+        ms = C.c_float()
+        self._chk(self.lib.kfpos_timing_end(self._h, _ptr(stream), C.byref(ms)))
+        return float(ms.value)

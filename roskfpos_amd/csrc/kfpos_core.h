@@ -1,0 +1,891 @@
+/*
+ * kfpos_core.h -- per-tag arithmetic of the batched EKF core (one filter per lane).
+ *
+ * This is the body every HIP kernel in kfpos_kernels.hip runs for one tag. It is written
+ * against plain doubles and compile-time-indexed arrays only (everything unrolls into
+ * registers; no HIP intrinsic appears here), so the same text also compiles with g++ into
+ * the host emulation used by the CPU tests (tests/emu) to check the algebra without a GPU.
+ *
+ * What it computes is the reference's iterated EKF, restructured
+ * for a register-resident, branch-light evaluation -- results equal the reference's to
+ * rounding (parity tests: <= 1e-6 m RMS required, ~1e-12 m observed):
+ *
+ *  - H has non-zero columns only for position (and, with the IMU rows, acceleration), and R is
+ *    diagonal (+ one 3x3 block), so with B = H restricted to those columns E and M = B' R^-1 B
+ *        H' S^-1 v = E' (I + M P_ee)^-1 B' R^-1 v          (Woodbury; S = H P H' + R)
+ *    replaces the reference's m x m inverse (KalmanFilterTOA.cpp:316-317) by a 3x3 (6-state) or
+ *    6x6 (9-state) solve that does not grow with the anchor count.
+ *  - the state after a gain iteration is x = xhat + P E' w, hence delta = xhat - x = -P E' w and
+ *        delta' pinv(P) delta = w' P_ee w = -w . delta_e
+ *    for symmetric PSD P of any rank (and for any invertible P), which removes the reference's
+ *    pinv(P) (KalmanFilterTOA.cpp:290): it only ever feeds the convergence cost.
+ *  - P+ = (I - K H) P = P - P E' N E P with N = (I + M P_ee)^-1 M (KalmanFilterTOA.cpp:326).
+ *  - F and Q are closed-form in dt (KalmanFilterTOA.cpp:362-391, KalmanFilterTOAIMU.cpp:392-421),
+ *    so x <- F x, P <- F P F' + Q is a structured update of the packed covariance, not a GEMM.
+ *
+ * Reference quirks kept on purpose: velocity (6-state) / acceleration (9-state)
+ * restart at 0 every step; the ML loop's first comparison is against the constant 1; the ML-init
+ * covariance copy repeats column 1 (6-state, which makes P non-symmetric: COV_FULL layout);
+ * H_imu = diag(a) instead of I; R = max(e_ML, errEst).
+ */
+#ifndef KFPOS_CORE_H
+#define KFPOS_CORE_H
+
+#include <math.h>
+#include <stdint.h>
+
+#ifndef KFPOS_HD
+#define KFPOS_HD
+#endif
+#if defined(__clang__)
+#define KFPOS_UNROLL _Pragma("unroll")
+#else
+#define KFPOS_UNROLL
+#endif
+
+namespace kfpos {
+
+/* per-tag status word (include/kfpos.h repeats these as KFPOS_ST_*) */
+enum : uint32_t {
+    ST_UPDATE_SKIPPED = 0x01u, /* the reference's swallowed std::runtime_error (KalmanFilterTOA.cpp:151-153) */
+    ST_ML_FALLBACK    = 0x02u, /* ML position NaN -> predicted position (KalmanFilterTOA.cpp:270-272) */
+    ST_FEW_RANGES     = 0x04u, /* < 4 ranges: ML returns its seed (MLLocation.cpp:158-161) */
+    ST_ML_INIT        = 0x08u, /* this call was the ML initialisation (KalmanFilterTOA.cpp:90-108) */
+    ST_NOT_STARTED    = 0x10u, /* getPose before any measurement (KalmanFilterTOA.cpp:442-447) */
+    ST_NONFINITE      = 0x20u, /* state not finite after the call */
+};
+/* persisted per-tag flag bits */
+enum : uint32_t { FL_STARTED = 1u, FL_HAS_IMU = 2u };
+
+KFPOS_HD inline uint32_t pack_status(uint32_t flags, int gain_iters, int ml_iters, int ignored) {
+    const uint32_t g = gain_iters > 255 ? 255u : (uint32_t)gain_iters;
+    const uint32_t m = ml_iters > 255 ? 255u : (uint32_t)ml_iters;
+    return flags | (g << 8) | (m << 16) | ((uint32_t)(ignored + 1) << 24);
+}
+
+/* std::max as the reference uses it: (a < b) ? b : a (matters for NaN) */
+KFPOS_HD inline double stdmax(double a, double b) { return (a < b) ? b : a; }
+
+/* ------------------------------------------------------------------ covariance storage */
+/* Packed upper triangle (symmetric) or full row-major. All indices are compile-time after
+ * unrolling, so the array lives in registers. */
+template <int N, bool SYMM>
+struct Cov {
+    static constexpr int SZ = SYMM ? N * (N + 1) / 2 : N * N;
+    double a[SZ];
+    KFPOS_HD static constexpr int idx(int i, int j) {
+        return SYMM ? (i <= j ? i * N - i * (i - 1) / 2 + (j - i) : j * N - j * (j - 1) / 2 + (i - j))
+                    : i * N + j;
+    }
+    KFPOS_HD double operator()(int i, int j) const { return a[idx(i, j)]; }
+    KFPOS_HD double &operator()(int i, int j) { return a[idx(i, j)]; }
+};
+
+/* Uniform (per-launch) parameters. anchors: xyz triples, wave-uniform reads. */
+struct Params {
+    const double *anchors;
+    int n_anchors;
+    double accel_noise, jolt, cost_threshold;
+    int ignore_worst, top_n, use_init_pos;
+};
+
+/* ------------------------------------------------------------------ 3x3 helpers */
+/* inverse of a symmetric 3x3 {00,01,02,11,12,22} by cofactors; returns det */
+KFPOS_HD inline double sym3_cofactors(const double h[6], double c[6]) {
+    c[0] = h[3] * h[5] - h[4] * h[4];
+    c[1] = h[2] * h[4] - h[1] * h[5];
+    c[2] = h[1] * h[4] - h[2] * h[3];
+    c[3] = h[0] * h[5] - h[2] * h[2];
+    c[4] = h[1] * h[2] - h[0] * h[4];
+    c[5] = h[0] * h[3] - h[1] * h[1];
+    return h[0] * c[0] + h[1] * c[1] + h[2] * c[2];
+}
+/* adjugate of a general 3x3 (row-major), returns det; inverse = adj / det */
+KFPOS_HD inline double gen3_adjugate(const double m[9], double adj[9]) {
+    adj[0] = m[4] * m[8] - m[5] * m[7];
+    adj[1] = m[2] * m[7] - m[1] * m[8];
+    adj[2] = m[1] * m[5] - m[2] * m[4];
+    adj[3] = m[5] * m[6] - m[3] * m[8];
+    adj[4] = m[0] * m[8] - m[2] * m[6];
+    adj[5] = m[2] * m[3] - m[0] * m[5];
+    adj[6] = m[3] * m[7] - m[4] * m[6];
+    adj[7] = m[1] * m[6] - m[0] * m[7];
+    adj[8] = m[0] * m[4] - m[1] * m[3];
+    return m[0] * adj[0] + m[1] * adj[3] + m[2] * adj[6];
+}
+
+/* Lower Cholesky of a symmetric PSD 3x3 {00,01,02,11,12,22}; a pivot that cancels to
+ * rounding level marks a rank-deficient direction (fewer than 3 independent ranges): its
+ * column is zeroed, which is the semidefinite factor (M = L L' still holds).
+ * l = {l00,l10,l20,l11,l21,l22}, il = reciprocals of the diagonal (0 for a dropped column). */
+KFPOS_HD inline void chol3_psd(const double m[6], double l[6], double il[3]) {
+    const double REL = 1e-12;
+    double d = m[0];
+    bool ok = d > 0.0;
+    l[0] = ok ? sqrt(d) : 0.0;
+    il[0] = ok ? 1.0 / l[0] : 0.0;
+    l[1] = m[1] * il[0];
+    l[2] = m[2] * il[0];
+    d = m[3] - l[1] * l[1];
+    ok = d > REL * m[3];
+    l[3] = ok ? sqrt(d) : 0.0;
+    il[1] = ok ? 1.0 / l[3] : 0.0;
+    l[4] = (m[4] - l[2] * l[1]) * il[1];
+    d = m[5] - l[2] * l[2] - l[4] * l[4];
+    ok = d > REL * m[5];
+    l[5] = ok ? sqrt(d) : 0.0;
+    il[2] = ok ? 1.0 / l[5] : 0.0;
+}
+
+/* ------------------------------------------------------------------ measurement scratch */
+/* Per-lane view of one tag's epoch: r = range in metres (<= 0: absent), e = errorEstimation,
+ * w = working weight (1/e during ML, 1/R during the IEKF). Element a lives at base[a*stride]:
+ * stride = wavefront width in LDS (conflict-free), 1 in the host emulation. */
+struct Scratch {
+    double *r, *e, *w;
+    int stride;
+    KFPOS_HD double R(int a) const { return r[a * stride]; }
+    KFPOS_HD double E(int a) const { return e[a * stride]; }
+    KFPOS_HD double W(int a) const { return w[a * stride]; }
+    KFPOS_HD void setW(int a, double v) const { w[a * stride] = v; }
+};
+KFPOS_HD inline bool used(const Scratch &sc, int a, uint64_t drop) {
+    return sc.R(a) > 0.0 && !((drop >> a) & 1ull);
+}
+KFPOS_HD inline int count_used(const Scratch &sc, int A, uint64_t drop) {
+    int n = 0;
+    for (int a = 0; a < A; ++a) n += used(sc, a, drop) ? 1 : 0;
+    return n;
+}
+
+/* ------------------------------------------------------------------ MLLocation::estimatePosition */
+/* One sweep over the anchors at position p: weighted cost sum (r-d)^2/e, unweighted SSE
+ * (estimationError, MLLocation.cpp:263-278), gradient g and Hessian-like Hs of
+ * MLLocation.cpp:174-204 (Hs symmetric, packed {00,01,02,11,12,22}). */
+KFPOS_HD inline void ml_sweep(const double p[3], const Scratch &sc, const Params &pr, uint64_t drop,
+                              double &cw, double &sse, double g[3], double hs[6]) {
+    cw = 0.0;
+    sse = 0.0;
+    g[0] = g[1] = g[2] = 0.0;
+    KFPOS_UNROLL
+    for (int k = 0; k < 6; ++k) hs[k] = 0.0;
+    for (int a = 0; a < pr.n_anchors; ++a) {
+        if (!used(sc, a, drop)) continue;
+        const double r = sc.R(a), w = sc.W(a);
+        const double dx = pr.anchors[3 * a] - p[0], dy = pr.anchors[3 * a + 1] - p[1],
+                     dz = pr.anchors[3 * a + 2] - p[2];
+        const double d = sqrt(dx * dx + dy * dy + dz * dz);
+        const double rd = r - d, invd = 1.0 / d;
+        cw += rd * rd * w;
+        sse += rd * rd;
+        const double gi = rd * invd * w;
+        g[0] += gi * dx;
+        g[1] += gi * dy;
+        g[2] += gi * dz;
+        const double q = r * invd;
+        const double c0 = w * (1.0 - q), c1 = w * q * invd * invd;
+        hs[0] += c0 + c1 * dx * dx;
+        hs[1] += c1 * dx * dy;
+        hs[2] += c1 * dx * dz;
+        hs[3] += c0 + c1 * dy * dy;
+        hs[4] += c1 * dy * dz;
+        hs[5] += c0 + c1 * dz * dz;
+    }
+}
+
+/* SSE only (estimationError at a given position) */
+KFPOS_HD inline double ml_sse(const double p[3], const Scratch &sc, const Params &pr, uint64_t drop) {
+    double sse = 0.0;
+    for (int a = 0; a < pr.n_anchors; ++a) {
+        if (!used(sc, a, drop)) continue;
+        const double dx = pr.anchors[3 * a] - p[0], dy = pr.anchors[3 * a + 1] - p[1],
+                     dz = pr.anchors[3 * a + 2] - p[2];
+        const double rd = sqrt(dx * dx + dy * dy + dz * dz) - sc.R(a);
+        sse += rd * rd;
+    }
+    return sse;
+}
+
+/* Gauss-Newton loop of MLLocation.cpp:164-225. p: seed in, estimate out. Requires sc.w = 1/e.
+ * Returns the iteration count; sse_out = estimationError at the result. With n_used < 4 the
+ * seed is returned untouched (MLLocation.cpp:158-161). The step p - Hs^-1 g equals the
+ * reference's solve(Hs, Hs p - g). */
+KFPOS_HD inline int ml_estimate(double p[3], const Scratch &sc, const Params &pr, uint64_t drop,
+                                int n_used, double &sse_out) {
+    if (n_used < 4) {
+        sse_out = (n_used == 0) ? -1.0 : ml_sse(p, sc, pr, drop);
+        return 0;
+    }
+    double cost = 1e20, newCost = 1.0, cw, sse, g[3], hs[6], c[6];
+    int iter = 0;
+    ml_sweep(p, sc, pr, drop, cw, sse, g, hs);
+    while ((fabs(cost - newCost) / cost > 1e-3) && (iter < 10000)) {
+        iter += 1;
+        cost = newCost;
+        const double det = sym3_cofactors(hs, c);
+        const double idet = 1.0 / det;
+        p[0] -= (c[0] * g[0] + c[1] * g[1] + c[2] * g[2]) * idet;
+        p[1] -= (c[1] * g[0] + c[3] * g[1] + c[4] * g[2]) * idet;
+        p[2] -= (c[2] * g[0] + c[4] * g[1] + c[5] * g[2]) * idet;
+        ml_sweep(p, sc, pr, drop, cw, sse, g, hs);
+        newCost = cw;
+    }
+    sse_out = sse;
+    return iter;
+}
+
+/* covariance of the ML estimate, inv(J' diag(max(e, e_ML))^-1 J) (MLLocation.cpp:229-252);
+ * symmetric 3x3 packed. Only the ML initialisation uses it. */
+KFPOS_HD inline void ml_covariance(const double p[3], const Scratch &sc, const Params &pr, double sse,
+                                   double cov[6]) {
+    double m[6] = {0, 0, 0, 0, 0, 0}, c[6];
+    for (int a = 0; a < pr.n_anchors; ++a) {
+        if (!used(sc, a, 0)) continue;
+        const double dx = p[0] - pr.anchors[3 * a], dy = p[1] - pr.anchors[3 * a + 1],
+                     dz = p[2] - pr.anchors[3 * a + 2];
+        const double invd = 1.0 / sqrt(dx * dx + dy * dy + dz * dz);
+        const double w = 1.0 / stdmax(sc.E(a), sse);
+        const double gx = dx * invd, gy = dy * invd, gz = dz * invd;
+        m[0] += w * gx * gx; m[1] += w * gx * gy; m[2] += w * gx * gz;
+        m[3] += w * gy * gy; m[4] += w * gy * gz; m[5] += w * gz * gz;
+    }
+    const double idet = 1.0 / sym3_cofactors(m, c);
+    KFPOS_UNROLL
+    for (int k = 0; k < 6; ++k) cov[k] = c[k] * idet;
+}
+
+KFPOS_HD inline void set_weights_ml(const Scratch &sc, int A) {
+    for (int a = 0; a < A; ++a) sc.setW(a, 1.0 / sc.E(a));
+}
+KFPOS_HD inline void set_weights_iekf(const Scratch &sc, int A, double e_ml) {
+    for (int a = 0; a < A; ++a) sc.setW(a, 1.0 / stdmax(e_ml, sc.E(a))); /* KalmanFilterTOA.cpp:281 */
+}
+
+/* Top-N composition (BASELINE config 5; MLLocation.cpp:284-300, 325-339): rank the residual^2
+ * at the ML position of all ranges, drop the min(n-4, N) largest. Returns the drop mask. */
+KFPOS_HD inline uint64_t topn_mask(const double seed[3], const Scratch &sc, const Params &pr, int n_valid) {
+    int ndrop = n_valid - 4 < pr.top_n ? n_valid - 4 : pr.top_n;
+    if (ndrop <= 0) return 0;
+    double p[3] = {seed[0], seed[1], seed[2]}, sse;
+    set_weights_ml(sc, pr.n_anchors);
+    ml_estimate(p, sc, pr, 0, n_valid, sse);
+    uint64_t drop = 0;
+    for (int k = 0; k < ndrop; ++k) {
+        double worst = -1.0;
+        int wi = -1;
+        for (int a = 0; a < pr.n_anchors; ++a) {
+            if (!used(sc, a, drop)) continue;
+            const double dx = pr.anchors[3 * a] - p[0], dy = pr.anchors[3 * a + 1] - p[1],
+                         dz = pr.anchors[3 * a + 2] - p[2];
+            const double rd = sqrt(dx * dx + dy * dy + dz * dz) - sc.R(a);
+            if (rd * rd > worst) { worst = rd * rd; wi = a; }
+        }
+        if (wi < 0) break;
+        drop |= 1ull << wi;
+    }
+    return drop;
+}
+
+/* ================================================================== 6-state filter (KalmanFilterTOA) */
+template <bool SYMM>
+struct Tag6 {
+    double pos[3];
+    Cov<6, SYMM> P;
+};
+
+/* x <- F x is the identity on position (velocity restarts at 0); P <- F P F' + Q.
+ * KalmanFilterTOA.cpp:115-123, 362-391. */
+template <bool SYMM>
+KFPOS_HD inline void predict6(Cov<6, SYMM> &P, double t, double accel_noise) {
+    const double t2 = (t * t) / 2, a2 = accel_noise * accel_noise;
+    KFPOS_UNROLL
+    for (int i = 0; i < 3; ++i) {
+        KFPOS_UNROLL
+        for (int j = SYMM ? i : 0; j < 3; ++j) {
+            /* pp += t (pv + vp) + t^2 vv */
+            P(i, j) = P(i, j) + t * (P(i, 3 + j) + P(3 + i, j)) + (t * t) * P(3 + i, 3 + j);
+        }
+    }
+    KFPOS_UNROLL
+    for (int i = 0; i < 3; ++i) {
+        KFPOS_UNROLL
+        for (int j = 0; j < 3; ++j) {
+            P(i, 3 + j) = P(i, 3 + j) + t * P(3 + i, 3 + j);
+            if (!SYMM) P(3 + i, j) = P(3 + i, j) + t * P(3 + i, 3 + j);
+        }
+    }
+    KFPOS_UNROLL
+    for (int k = 0; k < 3; ++k) {
+        P(k, k) += a2 * t2 * t2;
+        P(k, 3 + k) += a2 * t2 * t;
+        if (!SYMM) P(3 + k, k) += a2 * t2 * t;
+        P(3 + k, 3 + k) += a2 * t * t;
+    }
+}
+
+struct Iekf6Out {
+    double p[3];      /* updated position */
+    double mlast[6];  /* M = G' R^-1 G of the last gain iteration */
+    double cost;
+    int gain_iters, ml_iters;
+    uint32_t flags;
+};
+
+/* kalmanStep3DIgnoreAnchor (KalmanFilterTOA.cpp:242-338) up to, not including, the covariance
+ * update. xhat_p: predicted position; P: predicted covariance; drop: ignored anchors. */
+template <bool SYMM>
+KFPOS_HD inline void iekf6(const double xhat_p[3], const Cov<6, SYMM> &P, const Scratch &sc,
+                           const Params &pr, uint64_t drop, int n_used, int max_steps, double tol,
+                           Iekf6Out &o) {
+    o.flags = (n_used < 4) ? ST_FEW_RANGES : 0u;
+    /* ML position -> observation covariance (KalmanFilterTOA.cpp:268-282) */
+    double pml[3] = {xhat_p[0], xhat_p[1], xhat_p[2]}, e_ml;
+    set_weights_ml(sc, pr.n_anchors);
+    o.ml_iters = ml_estimate(pml, sc, pr, drop, n_used, e_ml);
+    if (isnan(pml[0]) || isnan(pml[1]) || isnan(pml[2])) {
+        o.flags |= ST_ML_FALLBACK;
+        e_ml = (n_used == 0) ? -1.0 : ml_sse(xhat_p, sc, pr, drop);
+    }
+    set_weights_iekf(sc, pr.n_anchors, e_ml);
+
+    double p[3] = {xhat_p[0], xhat_p[1], xhat_p[2]};
+    double dp[3] = {0.0, 0.0, 0.0}; /* delta_p = xhat_p - p */
+    double qd = 0.0;               /* delta' pinv(P) delta */
+    double cost = 1e20;
+    KFPOS_UNROLL
+    for (int k = 0; k < 6; ++k) o.mlast[k] = 0.0;
+    o.gain_iters = 0;
+    for (int iter = 0; iter < max_steps; ++iter) {
+        double c = qd, m[6] = {0, 0, 0, 0, 0, 0}, u[3] = {0, 0, 0};
+        for (int a = 0; a < pr.n_anchors; ++a) {
+            if (!used(sc, a, drop)) continue;
+            const double dx = p[0] - pr.anchors[3 * a], dy = p[1] - pr.anchors[3 * a + 1],
+                         dz = p[2] - pr.anchors[3 * a + 2];
+            const double d = sqrt(dx * dx + dy * dy + dz * dz);
+            const double w = sc.W(a), y = sc.R(a) - d, invd = 1.0 / d;
+            c += y * y * w;
+            const double gx = dx * invd, gy = dy * invd, gz = dz * invd;
+            const double v = (y - (gx * dp[0] + gy * dp[1] + gz * dp[2])) * w;
+            u[0] += gx * v; u[1] += gy * v; u[2] += gz * v;
+            const double wx = w * gx, wy = w * gy, wz = w * gz;
+            m[0] += wx * gx; m[1] += wx * gy; m[2] += wx * gz;
+            m[3] += wy * gy; m[4] += wy * gz; m[5] += wz * gz;
+        }
+        if (fabs(cost - c) / cost < tol) break; /* KalmanFilterTOA.cpp:307 */
+        cost = c;
+        KFPOS_UNROLL
+        for (int k = 0; k < 6; ++k) o.mlast[k] = m[k];
+        /* w3 = (I + M Ppp)^-1 u */
+        const double mm[3][3] = {{m[0], m[1], m[2]}, {m[1], m[3], m[4]}, {m[2], m[4], m[5]}};
+        double a33[9], adj[9];
+        KFPOS_UNROLL
+        for (int i = 0; i < 3; ++i) {
+            KFPOS_UNROLL
+            for (int j = 0; j < 3; ++j)
+                a33[3 * i + j] = (i == j ? 1.0 : 0.0) + mm[i][0] * P(0, j) + mm[i][1] * P(1, j) + mm[i][2] * P(2, j);
+        }
+        const double idet = 1.0 / gen3_adjugate(a33, adj);
+        double w3[3];
+        KFPOS_UNROLL
+        for (int i = 0; i < 3; ++i) w3[i] = (adj[3 * i] * u[0] + adj[3 * i + 1] * u[1] + adj[3 * i + 2] * u[2]) * idet;
+        qd = 0.0;
+        KFPOS_UNROLL
+        for (int i = 0; i < 3; ++i) {
+            const double s = P(i, 0) * w3[0] + P(i, 1) * w3[1] + P(i, 2) * w3[2];
+            p[i] = xhat_p[i] + s;
+            dp[i] = -s;
+            qd += w3[i] * s;
+        }
+        o.gain_iters++;
+    }
+    o.p[0] = p[0]; o.p[1] = p[1]; o.p[2] = p[2];
+    o.cost = cost;
+}
+
+/* P <- (I - K H) P = P - P[:,0:3] N P[0:3,:], N = (I + M Ppp)^-1 M (KalmanFilterTOA.cpp:326) */
+template <bool SYMM>
+KFPOS_HD inline void cov_update6(Cov<6, SYMM> &P, const double m[6]) {
+    const double mm[3][3] = {{m[0], m[1], m[2]}, {m[1], m[3], m[4]}, {m[2], m[4], m[5]}};
+    double a33[9], adj[9], nn[3][3];
+    KFPOS_UNROLL
+    for (int i = 0; i < 3; ++i) {
+        KFPOS_UNROLL
+        for (int j = 0; j < 3; ++j)
+            a33[3 * i + j] = (i == j ? 1.0 : 0.0) + mm[i][0] * P(0, j) + mm[i][1] * P(1, j) + mm[i][2] * P(2, j);
+    }
+    const double idet = 1.0 / gen3_adjugate(a33, adj);
+    KFPOS_UNROLL
+    for (int i = 0; i < 3; ++i) {
+        KFPOS_UNROLL
+        for (int j = 0; j < 3; ++j)
+            nn[i][j] = (adj[3 * i] * mm[0][j] + adj[3 * i + 1] * mm[1][j] + adj[3 * i + 2] * mm[2][j]) * idet;
+    }
+    /* V = N P[0:3,:] (3x6), then P(i,j) -= sum_k P(i,k) V(k,j) using the old P(:,0:3) column block */
+    double v[3][6], c0[6][3];
+    KFPOS_UNROLL
+    for (int k = 0; k < 3; ++k) {
+        KFPOS_UNROLL
+        for (int j = 0; j < 6; ++j) v[k][j] = nn[k][0] * P(0, j) + nn[k][1] * P(1, j) + nn[k][2] * P(2, j);
+    }
+    KFPOS_UNROLL
+    for (int i = 0; i < 6; ++i) {
+        KFPOS_UNROLL
+        for (int k = 0; k < 3; ++k) c0[i][k] = P(i, k);
+    }
+    KFPOS_UNROLL
+    for (int i = 0; i < 6; ++i) {
+        KFPOS_UNROLL
+        for (int j = SYMM ? i : 0; j < 6; ++j)
+            P(i, j) = P(i, j) - (c0[i][0] * v[0][j] + c0[i][1] * v[1][j] + c0[i][2] * v[2][j]);
+    }
+}
+
+/* KalmanFilterTOA::estimatePositionKF (KalmanFilterTOA.cpp:70-156) for one tag and one epoch.
+ * sc holds the epoch (r in metres, e). Returns the status word. */
+template <bool SYMM>
+KFPOS_HD inline uint32_t step_toa6(Tag6<SYMM> &tg, const Scratch &sc, const Params &pr, double dt) {
+    const int A = pr.n_anchors;
+    int n_valid = count_used(sc, A, 0);
+    if (!pr.use_init_pos && (isnan(tg.pos[0]) || isnan(tg.pos[1]) || isnan(tg.pos[2]))) {
+        /* ML initialisation, KalmanFilterTOA.cpp:90-108 (only the COV_FULL layout gets here) */
+        if (n_valid < 4) return ST_FEW_RANGES;
+        double p[3] = {1.0, 1.0, 4.0}, sse, c[6];
+        set_weights_ml(sc, A);
+        const int it = ml_estimate(p, sc, pr, 0, n_valid, sse);
+        ml_covariance(p, sc, pr, sse, c);
+        tg.pos[0] = p[0]; tg.pos[1] = p[1]; tg.pos[2] = p[2];
+        const double cm[3][3] = {{c[0], c[1], c[2]}, {c[1], c[3], c[4]}, {c[2], c[4], c[5]}};
+        KFPOS_UNROLL
+        for (int i = 0; i < 3; ++i) {
+            tg.P(i, 0) = cm[i][0];
+            tg.P(i, 1) = cm[i][1];
+            if (!SYMM) tg.P(i, 2) = cm[i][1]; /* sic: column 1 again (KalmanFilterTOA.cpp:102-104) */
+        }
+        if (SYMM) tg.P(2, 2) = cm[2][1];
+        return pack_status(ST_ML_INIT, 0, it, -1);
+    }
+    uint64_t drop = 0;
+    if (pr.top_n > 0 && !(isnan(tg.pos[0]) || isnan(tg.pos[1]) || isnan(tg.pos[2]))) {
+        drop = topn_mask(tg.pos, sc, pr, n_valid);
+        n_valid = count_used(sc, A, drop);
+    }
+    predict6(tg.P, dt, pr.accel_noise);
+    const double xhat_p[3] = {tg.pos[0], tg.pos[1], tg.pos[2]};
+
+    Iekf6Out o;
+    int ignored = -1;
+    uint64_t chosen = drop;
+    if (n_valid > 4 && pr.ignore_worst) {
+        /* kalmanStep3DCanIgnoreAnAnchor, KalmanFilterTOA.cpp:185-238: one solve with every range,
+         * one per left-out range; the winner is then re-solved for its covariance. */
+        iekf6(xhat_p, tg.P, sc, pr, drop, n_valid, 10, 1e-3, o);
+        const double cost_all = o.cost;
+        double max_distance = 0.0, worst_cost = 0.0;
+        int best_a = -1, best_i = -1, i = 0;
+        for (int a = 0; a < A; ++a) {
+            if (!used(sc, a, drop)) continue;
+            iekf6(xhat_p, tg.P, sc, pr, drop | (1ull << a), n_valid - 1, 10, 1e-3, o);
+            const double dx = pr.anchors[3 * a] - o.p[0], dy = pr.anchors[3 * a + 1] - o.p[1],
+                         dz = pr.anchors[3 * a + 2] - o.p[2];
+            const double diff = sc.R(a) - sqrt(dx * dx + dy * dy + dz * dz);
+            if (i == 0 || diff > max_distance) {
+                max_distance = diff;
+                worst_cost = o.cost;
+                best_a = a;
+                best_i = i;
+            }
+            ++i;
+        }
+        if (max_distance > 0.0 && (cost_all - worst_cost) > pr.cost_threshold) {
+            chosen = drop | (1ull << best_a);
+            ignored = best_i;
+            n_valid -= 1;
+        }
+    }
+    iekf6(xhat_p, tg.P, sc, pr, chosen, n_valid, 10, 1e-3, o);
+    cov_update6(tg.P, o.mlast);
+    tg.pos[0] = o.p[0]; tg.pos[1] = o.p[1]; tg.pos[2] = o.p[2];
+    return pack_status(o.flags, o.gain_iters, o.ml_iters, ignored);
+}
+
+/* getPose (KalmanFilterTOA.cpp:438-473): predict-only; position block of F P F' + Q */
+template <bool SYMM>
+KFPOS_HD inline void pose6(const Tag6<SYMM> &tg, double t, double accel_noise, double pos[3], double cov[9]) {
+    const double t2 = (t * t) / 2, a2 = accel_noise * accel_noise;
+    KFPOS_UNROLL
+    for (int i = 0; i < 3; ++i) {
+        pos[i] = tg.pos[i];
+        KFPOS_UNROLL
+        for (int j = 0; j < 3; ++j)
+            cov[3 * i + j] = tg.P(i, j) + t * (tg.P(i, 3 + j) + tg.P(3 + i, j)) + (t * t) * tg.P(3 + i, 3 + j) +
+                             (i == j ? a2 * t2 * t2 : 0.0);
+    }
+}
+
+/* ================================================================== 9-state filter (KalmanFilterTOAIMU) */
+struct Tag9 {
+    double pos[3], vel[3];
+    Cov<9, true> P;
+};
+struct Imu {
+    bool has;      /* hasImuMeasurement */
+    double acc[3]; /* linearAcceleration */
+    double ci[6];  /* inverse Cholesky factor of the covariance, lower {00,10,20,11,21,22}: Sigma^-1 = Ci' Ci */
+};
+
+/* Sigma (row-major 3x3, symmetric positive definite) -> Ci with Sigma^-1 = Ci' Ci */
+KFPOS_HD inline void imu_whitener(const double s[9], double ci[6]) {
+    const double c00 = sqrt(s[0]);
+    const double c10 = s[3] / c00, c20 = s[6] / c00;
+    const double c11 = sqrt(s[4] - c10 * c10);
+    const double c21 = (s[7] - c20 * c10) / c11;
+    const double c22 = sqrt(s[8] - c20 * c20 - c21 * c21);
+    const double i00 = 1.0 / c00, i11 = 1.0 / c11, i22 = 1.0 / c22;
+    const double i10 = -c10 * i00 * i11;
+    const double i21 = -c21 * i11 * i22;
+    const double i20 = -(c20 * i00 + c21 * i10) * i22;
+    ci[0] = i00; ci[1] = i10; ci[2] = i20; ci[3] = i11; ci[4] = i21; ci[5] = i22;
+}
+
+/* KalmanFilterTOAIMU.cpp:170-180, 392-421 */
+KFPOS_HD inline void predict9(Cov<9, true> &P, double t, double jolt) {
+    const double c = t * t / 2;
+    /* blocks: p = 0..2, v = 3..5, a = 6..8; each block is updated from not-yet-overwritten ones */
+    KFPOS_UNROLL
+    for (int i = 0; i < 3; ++i) {
+        KFPOS_UNROLL
+        for (int j = i; j < 3; ++j) {
+            const double xpp = P(i, j) + t * P(3 + i, j) + c * P(6 + i, j);
+            const double xpv = P(i, 3 + j) + t * P(3 + i, 3 + j) + c * P(6 + i, 3 + j);
+            const double xpa = P(i, 6 + j) + t * P(3 + i, 6 + j) + c * P(6 + i, 6 + j);
+            P(i, j) = xpp + t * xpv + c * xpa;
+        }
+    }
+    KFPOS_UNROLL
+    for (int i = 0; i < 3; ++i) {
+        KFPOS_UNROLL
+        for (int j = 0; j < 3; ++j) {
+            const double xpv = P(i, 3 + j) + t * P(3 + i, 3 + j) + c * P(6 + i, 3 + j);
+            const double xpa = P(i, 6 + j) + t * P(3 + i, 6 + j) + c * P(6 + i, 6 + j);
+            P(i, 3 + j) = xpv + t * xpa;
+        }
+    }
+    KFPOS_UNROLL
+    for (int i = 0; i < 3; ++i) {
+        KFPOS_UNROLL
+        for (int j = 0; j < 3; ++j) P(i, 6 + j) = P(i, 6 + j) + t * P(3 + i, 6 + j) + c * P(6 + i, 6 + j);
+    }
+    KFPOS_UNROLL
+    for (int i = 0; i < 3; ++i) {
+        KFPOS_UNROLL
+        for (int j = i; j < 3; ++j) {
+            const double xvv = P(3 + i, 3 + j) + t * P(6 + i, 3 + j);
+            const double xva = P(3 + i, 6 + j) + t * P(6 + i, 6 + j);
+            P(3 + i, 3 + j) = xvv + t * xva;
+        }
+    }
+    KFPOS_UNROLL
+    for (int i = 0; i < 3; ++i) {
+        KFPOS_UNROLL
+        for (int j = 0; j < 3; ++j) P(3 + i, 6 + j) = P(3 + i, 6 + j) + t * P(6 + i, 6 + j);
+    }
+    const double u[3] = {(t * t * t) / 6, (t * t) / 2, t};
+    KFPOS_UNROLL
+    for (int k = 0; k < 3; ++k) {
+        KFPOS_UNROLL
+        for (int a = 0; a < 3; ++a) {
+            KFPOS_UNROLL
+            for (int b = a; b < 3; ++b) P(k + 3 * a, k + 3 * b) += jolt * u[a] * u[b];
+        }
+    }
+}
+
+/* index of the k-th updated state component: position 0..2, acceleration 6..8 */
+KFPOS_HD constexpr int e9(int k) { return k < 3 ? k : k + 3; }
+
+/* L = blockdiag(L_r, L_a): M_r = L_r L_r' (lower, psd Cholesky), M_a = D Sigma^-1 D = L_a L_a'
+ * with L_a = D Ci' (upper). lt[k][l] = L(k, l) as a dense 6x6 with structural zeros. */
+struct Factor9 {
+    double lr[6], ilr[3]; /* chol3_psd of M_r */
+    double la[6];         /* upper {00,01,02,11,12,22}: la(k,l) = a_k * ci(l,k) */
+};
+KFPOS_HD inline void factor9(const double mr[6], const double acc[3], const Imu &imu, Factor9 &f) {
+    chol3_psd(mr, f.lr, f.ilr);
+    if (imu.has) {
+        f.la[0] = acc[0] * imu.ci[0]; f.la[1] = acc[0] * imu.ci[1]; f.la[2] = acc[0] * imu.ci[2];
+        f.la[3] = acc[1] * imu.ci[3]; f.la[4] = acc[1] * imu.ci[4];
+        f.la[5] = acc[2] * imu.ci[5];
+    } else {
+        KFPOS_UNROLL
+        for (int k = 0; k < 6; ++k) f.la[k] = 0.0;
+    }
+}
+/* dense access L(k,l), k,l in 0..5 (compile-time indices) */
+KFPOS_HD inline double L9(const Factor9 &f, int k, int l) {
+    if (k < 3 && l < 3) {
+        if (k < l) return 0.0;
+        /* lower packed {00,10,20,11,21,22} */
+        return f.lr[l == 0 ? k : (l == 1 ? 2 + k : 5)];
+    }
+    if (k >= 3 && l >= 3) {
+        const int i = k - 3, j = l - 3;
+        if (i > j) return 0.0;
+        return f.la[i == 0 ? j : (i == 1 ? 2 + j : 5)];
+    }
+    return 0.0;
+}
+
+struct Iekf9Out {
+    double x[9];
+    double mrlast[6], dlast[3];
+    double cost;
+    int gain_iters, ml_iters;
+    uint32_t flags;
+};
+
+/* kalmanStep3D (KalmanFilterTOAIMU.cpp:242-340, with the 3-token repair) up to the covariance update */
+KFPOS_HD inline void iekf9(const double xhat[9], const Cov<9, true> &P, const Scratch &sc, const Params &pr,
+                           bool has_ranging, int n_used, const Imu &imu, int max_steps, double tol,
+                           Iekf9Out &o) {
+    const uint64_t drop = has_ranging ? 0ull : ~0ull;
+    if (!has_ranging) n_used = 0;
+    o.flags = (has_ranging && n_used < 4) ? ST_FEW_RANGES : 0u;
+    o.ml_iters = 0;
+    if (has_ranging) {
+        double pml[3] = {xhat[0], xhat[1], xhat[2]}, e_ml;
+        set_weights_ml(sc, pr.n_anchors);
+        o.ml_iters = ml_estimate(pml, sc, pr, drop, n_used, e_ml); /* no NaN fallback in this filter */
+        set_weights_iekf(sc, pr.n_anchors, e_ml);
+    }
+    double p[3] = {xhat[0], xhat[1], xhat[2]}, acc[3] = {xhat[6], xhat[7], xhat[8]};
+    double de[6] = {0, 0, 0, 0, 0, 0}; /* delta on the updated components (position, acceleration) */
+    double wl[6] = {0, 0, 0, 0, 0, 0};
+    double qd = 0.0, cost = 1e20;
+    KFPOS_UNROLL
+    for (int k = 0; k < 6; ++k) o.mrlast[k] = 0.0;
+    o.dlast[0] = o.dlast[1] = o.dlast[2] = 0.0;
+    o.gain_iters = 0;
+    for (int iter = 0; iter < max_steps; ++iter) {
+        double c = qd, m[6] = {0, 0, 0, 0, 0, 0}, u[3] = {0, 0, 0};
+        for (int a = 0; a < pr.n_anchors; ++a) {
+            if (!used(sc, a, drop)) continue;
+            const double dx = p[0] - pr.anchors[3 * a], dy = p[1] - pr.anchors[3 * a + 1],
+                         dz = p[2] - pr.anchors[3 * a + 2];
+            const double d = sqrt(dx * dx + dy * dy + dz * dz);
+            const double w = sc.W(a), y = sc.R(a) - d, invd = 1.0 / d;
+            c += y * y * w;
+            const double gx = dx * invd, gy = dy * invd, gz = dz * invd;
+            const double v = (y - (gx * de[0] + gy * de[1] + gz * de[2])) * w;
+            u[0] += gx * v; u[1] += gy * v; u[2] += gz * v;
+            const double wx = w * gx, wy = w * gy, wz = w * gz;
+            m[0] += wx * gx; m[1] += wx * gy; m[2] += wx * gz;
+            m[3] += wy * gy; m[4] += wy * gz; m[5] += wz * gz;
+        }
+        double s[6] = {0, 0, 0, 0, 0, 0};
+        if (imu.has) {
+            /* y_a = z_a - a; cost += y_a' Sigma^-1 y_a = |Ci y_a|^2; s_a = Ci (y_a - D delta_a) */
+            const double ya[3] = {imu.acc[0] - acc[0], imu.acc[1] - acc[1], imu.acc[2] - acc[2]};
+            const double q0 = imu.ci[0] * ya[0];
+            const double q1 = imu.ci[1] * ya[0] + imu.ci[3] * ya[1];
+            const double q2 = imu.ci[2] * ya[0] + imu.ci[4] * ya[1] + imu.ci[5] * ya[2];
+            c += q0 * q0 + q1 * q1 + q2 * q2;
+            const double va[3] = {ya[0] - acc[0] * de[3], ya[1] - acc[1] * de[4], ya[2] - acc[2] * de[5]};
+            s[3] = imu.ci[0] * va[0];
+            s[4] = imu.ci[1] * va[0] + imu.ci[3] * va[1];
+            s[5] = imu.ci[2] * va[0] + imu.ci[4] * va[1] + imu.ci[5] * va[2];
+        }
+        if (fabs(cost - c) / cost < tol) break; /* KalmanFilterTOAIMU.cpp:316 */
+        cost = c;
+        KFPOS_UNROLL
+        for (int k = 0; k < 6; ++k) o.mrlast[k] = m[k];
+        o.dlast[0] = acc[0]; o.dlast[1] = acc[1]; o.dlast[2] = acc[2];
+
+        Factor9 f;
+        factor9(m, acc, imu, f);
+        /* L_r s_r = u_r (dropped columns give 0) */
+        s[0] = u[0] * f.ilr[0];
+        s[1] = (u[1] - f.lr[1] * s[0]) * f.ilr[1];
+        s[2] = (u[2] - f.lr[2] * s[0] - f.lr[4] * s[1]) * f.ilr[2];
+        /* T = I + L' P_ee L (6x6 symmetric, >= I) */
+        double pl[6][6]; /* P_ee L */
+        KFPOS_UNROLL
+        for (int i = 0; i < 6; ++i) {
+            KFPOS_UNROLL
+            for (int j = 0; j < 6; ++j) {
+                double acc_ = 0.0;
+                KFPOS_UNROLL
+                for (int k = 0; k < 6; ++k) {
+                    /* structural zeros of L fold away at compile time */
+                    const bool nz = (k < 3 && j < 3 && k >= j) || (k >= 3 && j >= 3 && k <= j);
+                    if (nz) acc_ += P(e9(i), e9(k)) * L9(f, k, j);
+                }
+                pl[i][j] = acc_;
+            }
+        }
+        Cov<6, true> T;
+        KFPOS_UNROLL
+        for (int i = 0; i < 6; ++i) {
+            KFPOS_UNROLL
+            for (int j = i; j < 6; ++j) {
+                double acc_ = (i == j) ? 1.0 : 0.0;
+                KFPOS_UNROLL
+                for (int k = 0; k < 6; ++k) {
+                    const bool nz = (k < 3 && i < 3 && k >= i) || (k >= 3 && i >= 3 && k <= i);
+                    if (nz) acc_ += L9(f, k, i) * pl[k][j];
+                }
+                T(i, j) = acc_;
+            }
+        }
+        /* LDL' of T (no pivoting needed: T is SPD with eigenvalues >= 1), solve T t = s */
+        double dinv[6];
+        KFPOS_UNROLL
+        for (int j = 0; j < 6; ++j) {
+            double d = T(j, j);
+            KFPOS_UNROLL
+            for (int k = 0; k < j; ++k) d -= T(k, j) * T(k, j) * dinv[k]; /* T(k,j) holds (L D)(j,k) */
+            dinv[j] = 1.0 / d;
+            KFPOS_UNROLL
+            for (int i = j + 1; i < 6; ++i) {
+                double v = T(j, i);
+                KFPOS_UNROLL
+                for (int k = 0; k < j; ++k) v -= T(k, i) * T(k, j) * dinv[k];
+                T(j, i) = v; /* = l(i,j) * d_j */
+            }
+        }
+        double tt[6];
+        KFPOS_UNROLL
+        for (int i = 0; i < 6; ++i) { /* forward: (L D) z' ... z = L^-1 s */
+            double v = s[i];
+            KFPOS_UNROLL
+            for (int k = 0; k < i; ++k) v -= T(k, i) * dinv[k] * tt[k];
+            tt[i] = v;
+        }
+        KFPOS_UNROLL
+        for (int i = 5; i >= 0; --i) { /* backward: L' t = D^-1 z */
+            double v = tt[i] * dinv[i];
+            KFPOS_UNROLL
+            for (int k = i + 1; k < 6; ++k) v -= T(i, k) * dinv[i] * tt[k];
+            tt[i] = v;
+        }
+        /* w = L t */
+        KFPOS_UNROLL
+        for (int i = 0; i < 6; ++i) {
+            double v = 0.0;
+            KFPOS_UNROLL
+            for (int k = 0; k < 6; ++k) {
+                const bool nz = (i < 3 && k < 3 && i >= k) || (i >= 3 && k >= 3 && i <= k);
+                if (nz) v += L9(f, i, k) * tt[k];
+            }
+            wl[i] = v;
+        }
+        /* x_e = xhat_e + P_ee w ; delta_e = -P_ee w ; delta' pinv(P) delta = w . P_ee w */
+        qd = 0.0;
+        KFPOS_UNROLL
+        for (int i = 0; i < 6; ++i) {
+            double v = 0.0;
+            KFPOS_UNROLL
+            for (int k = 0; k < 6; ++k) v += P(e9(i), e9(k)) * wl[k];
+            de[i] = -v;
+            qd += wl[i] * v;
+            if (i < 3) p[i] = xhat[i] + v;
+            else acc[i - 3] = xhat[3 + i] + v;
+        }
+        o.gain_iters++;
+    }
+    KFPOS_UNROLL
+    for (int i = 0; i < 9; ++i) {
+        double v = 0.0;
+        KFPOS_UNROLL
+        for (int k = 0; k < 6; ++k) v += P(i, e9(k)) * wl[k];
+        o.x[i] = xhat[i] + v;
+    }
+    o.cost = cost;
+}
+
+/* P <- (I - K H) P (KalmanFilterTOAIMU.cpp:338) as six rank-1 downdates along the columns of
+ * E' L (unit-noise pseudo-measurements): P -= (P t)(P t)' / (1 + t' P t). */
+KFPOS_HD inline void cov_update9(Cov<9, true> &P, const double mr[6], const double d[3], const Imu &imu) {
+    Factor9 f;
+    factor9(mr, d, imu, f);
+    KFPOS_UNROLL
+    for (int k = 0; k < 6; ++k) {
+        double pt[9], s = 1.0;
+        KFPOS_UNROLL
+        for (int i = 0; i < 9; ++i) {
+            double v = 0.0;
+            KFPOS_UNROLL
+            for (int l = 0; l < 6; ++l) {
+                const bool nz = (l < 3 && k < 3 && l >= k) || (l >= 3 && k >= 3 && l <= k);
+                if (nz) v += P(i, e9(l)) * L9(f, l, k);
+            }
+            pt[i] = v;
+        }
+        KFPOS_UNROLL
+        for (int l = 0; l < 6; ++l) {
+            const bool nz = (l < 3 && k < 3 && l >= k) || (l >= 3 && k >= 3 && l <= k);
+            if (nz) s += L9(f, l, k) * pt[e9(l)];
+        }
+        const double is = 1.0 / s;
+        KFPOS_UNROLL
+        for (int i = 0; i < 9; ++i) {
+            const double pi = pt[i] * is;
+            KFPOS_UNROLL
+            for (int j = i; j < 9; ++j) P(i, j) -= pi * pt[j];
+        }
+    }
+}
+
+/* KalmanFilterTOAIMU::estimatePositionKF (KalmanFilterTOAIMU.cpp:100-195) for one tag.
+ * has_ranging = false is the IMU-only call of newIMUMeasurement (:91). */
+KFPOS_HD inline uint32_t step_imu9(Tag9 &tg, const Scratch &sc, const Params &pr, double dt,
+                                   bool has_ranging, const Imu &imu) {
+    const int A = pr.n_anchors;
+    const int n_valid = has_ranging ? count_used(sc, A, 0) : 0;
+    if (!pr.use_init_pos && (isnan(tg.pos[0]) || isnan(tg.pos[1]))) { /* :121-122, z is not tested */
+        if (!has_ranging) return 0;
+        if (n_valid < 4) return ST_FEW_RANGES;
+        double p[3] = {1.0, 1.0, 4.0}, sse, c[6];
+        set_weights_ml(sc, A);
+        const int it = ml_estimate(p, sc, pr, 0, n_valid, sse);
+        ml_covariance(p, sc, pr, sse, c);
+        tg.pos[0] = p[0]; tg.pos[1] = p[1]; tg.pos[2] = p[2];
+        tg.P(0, 0) = c[0]; tg.P(0, 1) = c[1]; tg.P(1, 1) = c[3]; /* xy block only, :134-137 */
+        return pack_status(ST_ML_INIT, 0, it, -1);
+    }
+    predict9(tg.P, dt, pr.jolt);
+    const double c = dt * dt / 2;
+    double xhat[9];
+    KFPOS_UNROLL
+    for (int k = 0; k < 3; ++k) { /* acceleration restarts at 0 */
+        xhat[k] = tg.pos[k] + dt * tg.vel[k] + c * 0.0;
+        xhat[3 + k] = tg.vel[k] + dt * 0.0;
+        xhat[6 + k] = 0.0;
+    }
+    Iekf9Out o;
+    iekf9(xhat, tg.P, sc, pr, has_ranging, n_valid, imu, 20, 1e-4, o);
+    cov_update9(tg.P, o.mrlast, o.dlast, imu);
+    KFPOS_UNROLL
+    for (int k = 0; k < 3; ++k) { tg.pos[k] = o.x[k]; tg.vel[k] = o.x[3 + k]; } /* :189-194 */
+    return pack_status(o.flags, o.gain_iters, o.ml_iters, -1);
+}
+
+/* getPose (KalmanFilterTOAIMU.cpp:476-510): predicted position / velocity and the position block */
+KFPOS_HD inline void pose9(const Tag9 &tg, double t, double jolt, double pos[3], double vel[3], double cov[9]) {
+    const double c = t * t / 2, t3 = (t * t * t) / 6;
+    KFPOS_UNROLL
+    for (int i = 0; i < 3; ++i) {
+        pos[i] = tg.pos[i] + t * tg.vel[i];
+        vel[i] = tg.vel[i];
+        KFPOS_UNROLL
+        for (int j = 0; j < 3; ++j) {
+            const Cov<9, true> &P = tg.P;
+            const double xpp = P(i, j) + t * P(3 + i, j) + c * P(6 + i, j);
+            const double xpv = P(i, 3 + j) + t * P(3 + i, 3 + j) + c * P(6 + i, 3 + j);
+            const double xpa = P(i, 6 + j) + t * P(3 + i, 6 + j) + c * P(6 + i, 6 + j);
+            cov[3 * i + j] = xpp + t * xpv + c * xpa + (i == j ? jolt * t3 * t3 : 0.0);
+        }
+    }
+}
+
+} // namespace kfpos
+#endif

@@ -1,0 +1,804 @@
+/*
+ * kfpos_hip.hip -- HIP kernels (gfx950 / CDNA4) and the C ABI of include/kfpos.h.
+ *
+ * Execution model: ONE FILTER PER LANE, 64 filters per wavefront, one wavefront per workgroup.
+ *  - The whole per-tag state (position, velocity, packed covariance: 21 / 36 / 45 doubles) lives in
+ *    VGPRs for the duration of a step; every array index in kfpos_core.h is a compile-time constant
+ *    after unrolling. At 65 536 tags there is exactly one wavefront per SIMD (1024 waves on
+ *    256 CUs x 4 SIMDs), so the 512-register file per lane is free to use.
+ *  - HBM layout is component-major ([component][tag]): lane l of a wave reads element
+ *    base + tag0 + l, so every state / measurement access is one fully coalesced
+ *    512-byte (f64) or 256-byte (f32 / int32) wave transaction, each byte touched once.
+ *  - LDS holds the epoch's measurements per lane, [anchor][lane] (lane-consecutive 8-byte words:
+ *    conflict-free ds_read_b64): range in metres (the integer-mm wire value converted once, with the
+ *    reference's exact `(double) mm / 1000`, Posgenerator.cpp:484), errorEstimation, and the working
+ *    weight (1/e for the ML sweeps, 1/R for the IEKF sweeps). The inner sweeps (2-4 ML + 3-8 IEKF per
+ *    step) then touch only LDS + SGPRs, never HBM.
+ *  - Anchor coordinates are wave-uniform: they travel in the kernel-argument segment and are read
+ *    with scalar loads into SGPRs.
+ *  - No MFMA: the largest dense object is 9x9 per filter; no cross-lane traffic at all: lanes are
+ *    independent filters, so there is nothing to shuffle and no barrier in any kernel.
+ *
+ * Reference paths replaced: KalmanFilterTOA.cpp:70-156 / KalmanFilterTOAIMU.cpp:100-195 (step kernels),
+ * KalmanFilterTOA.cpp:438-473 / KalmanFilterTOAIMU.cpp:476-510 (pose kernel).
+ */
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#define KFPOS_HD __host__ __device__
+#include "kfpos_core.h"
+#include "../../include/kfpos.h"
+
+namespace {
+
+using namespace kfpos;
+
+constexpr int WAVE = 64; /* lanes per workgroup = one wavefront */
+
+enum StepMode : int { MODE_TOA = 0, MODE_IMU_ONLY = 1, MODE_FUSED = 2 };
+
+/* kernel arguments: everything wave-uniform, read through scalar loads */
+struct KArgs {
+    double anchors[KFPOS_MAX_ANCHORS * 3];
+    int T, A;
+    double accel_noise, jolt, cost_threshold;
+    int ignore_worst, top_n, use_init_pos;
+    /* persistent state, component-major */
+    double *pos;      /* [3][T] */
+    void *vel;        /* [3][T] real (9-state) */
+    void *P;          /* [SZ][T] real */
+    uint32_t *flags;  /* [T] */
+    void *imu_acc;    /* [3][T] real, latched sample (9-state) */
+    void *imu_cov;    /* [6][T] real, lower triangle {00,10,11,20,21,22} of the latched covariance */
+    /* epoch inputs */
+    const int32_t *ranges; /* [A][T] */
+    const void *err;       /* [A][T] real */
+    const double *dt;      /* [T] or null */
+    double dt_shared;
+    const void *accel;     /* [3][T] real */
+    const void *cov;       /* [9][T] real */
+    int mode, latch;
+    uint32_t *status;      /* [T] or null */
+};
+
+template <typename REAL>
+__device__ inline double ld(const void *p, size_t i) { return (double)((const REAL *)p)[i]; }
+template <typename REAL>
+__device__ inline void st(void *p, size_t i, double v) { ((REAL *)p)[i] = (REAL)v; }
+
+__device__ inline Params make_params(const KArgs &a) {
+    Params pr;
+    pr.anchors = a.anchors;
+    pr.n_anchors = a.A;
+    pr.accel_noise = a.accel_noise;
+    pr.jolt = a.jolt;
+    pr.cost_threshold = a.cost_threshold;
+    pr.ignore_worst = a.ignore_worst;
+    pr.top_n = a.top_n;
+    pr.use_init_pos = a.use_init_pos;
+    return pr;
+}
+
+/* epoch -> per-lane LDS scratch */
+template <typename REAL>
+__device__ inline Scratch stage_epoch(const KArgs &a, double *lds, int lane, size_t t) {
+    Scratch sc;
+    sc.r = lds + lane;
+    sc.e = lds + (size_t)a.A * WAVE + lane;
+    sc.w = lds + 2 * (size_t)a.A * WAVE + lane;
+    sc.stride = WAVE;
+    for (int k = 0; k < a.A; ++k) {
+        const int32_t mm = a.ranges[(size_t)k * a.T + t];
+        sc.r[k * WAVE] = mm > 0 ? (double)mm / 1000 : 0.0; /* Posgenerator.cpp:483-484 */
+        sc.e[k * WAVE] = ld<REAL>(a.err, (size_t)k * a.T + t);
+    }
+    return sc;
+}
+
+/* ------------------------------------------------------------------ 6-state step kernel */
+template <bool SYMM, typename REAL>
+__global__ __launch_bounds__(WAVE) void k_step_toa6(const KArgs a) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const size_t t = (size_t)blockIdx.x * WAVE + lane;
+    if (t >= (size_t)a.T) return;
+    const size_t T = a.T;
+    const Params pr = make_params(a);
+    const Scratch sc = stage_epoch<REAL>(a, lds, lane, t);
+
+    Tag6<SYMM> tg;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) tg.pos[k] = a.pos[k * T + t];
+#pragma unroll
+    for (int k = 0; k < Cov<6, SYMM>::SZ; ++k) tg.P.a[k] = ld<REAL>(a.P, k * T + t);
+    const double dt = a.dt ? a.dt[t] : a.dt_shared;
+
+    uint32_t s = step_toa6<SYMM>(tg, sc, pr, dt);
+
+    bool fin = true;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        a.pos[k * T + t] = tg.pos[k];
+        fin = fin && isfinite(tg.pos[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < Cov<6, SYMM>::SZ; ++k) {
+        st<REAL>(a.P, k * T + t, tg.P.a[k]);
+        fin = fin && isfinite(tg.P.a[k]);
+    }
+    const bool waiting = !a.use_init_pos && isnan(tg.pos[0]); /* still waiting for its ML initialisation */
+    if (!fin && !waiting) s |= ST_NONFINITE;
+    a.flags[t] |= FL_STARTED;
+    if (a.status) a.status[t] = s;
+}
+
+/* ------------------------------------------------------------------ 9-state step kernel */
+template <typename REAL>
+__global__ __launch_bounds__(WAVE) void k_step_imu9(const KArgs a) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const size_t t = (size_t)blockIdx.x * WAVE + lane;
+    if (t >= (size_t)a.T) return;
+    const size_t T = a.T;
+    const Params pr = make_params(a);
+    const bool has_ranging = a.mode != MODE_IMU_ONLY;
+    Scratch sc{nullptr, nullptr, nullptr, WAVE};
+    if (has_ranging) sc = stage_epoch<REAL>(a, lds, lane, t);
+
+    uint32_t fl = a.flags[t];
+    Imu imu;
+    imu.has = false;
+    double cv[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (a.mode != MODE_TOA) { /* fresh sample: newIMUMeasurement latches it (KalmanFilterTOAIMU.cpp:78-89) */
+        imu.has = true;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) imu.acc[k] = ld<REAL>(a.accel, k * T + t);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) cv[k] = ld<REAL>(a.cov, k * T + t);
+        if (a.latch) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) st<REAL>(a.imu_acc, k * T + t, imu.acc[k]);
+            st<REAL>(a.imu_cov, 0 * T + t, cv[0]);
+            st<REAL>(a.imu_cov, 1 * T + t, cv[3]);
+            st<REAL>(a.imu_cov, 2 * T + t, cv[4]);
+            st<REAL>(a.imu_cov, 3 * T + t, cv[6]);
+            st<REAL>(a.imu_cov, 4 * T + t, cv[7]);
+            st<REAL>(a.imu_cov, 5 * T + t, cv[8]);
+            fl |= FL_HAS_IMU;
+        }
+    } else if (fl & FL_HAS_IMU) { /* re-fuse the latched sample (KalmanFilterTOAIMU.cpp:68-72) */
+        imu.has = true;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) imu.acc[k] = ld<REAL>(a.imu_acc, k * T + t);
+        cv[0] = ld<REAL>(a.imu_cov, 0 * T + t);
+        cv[3] = ld<REAL>(a.imu_cov, 1 * T + t);
+        cv[4] = ld<REAL>(a.imu_cov, 2 * T + t);
+        cv[6] = ld<REAL>(a.imu_cov, 3 * T + t);
+        cv[7] = ld<REAL>(a.imu_cov, 4 * T + t);
+        cv[8] = ld<REAL>(a.imu_cov, 5 * T + t);
+    }
+    if (imu.has) imu_whitener(cv, imu.ci);
+
+    Tag9 tg;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        tg.pos[k] = a.pos[k * T + t];
+        tg.vel[k] = ld<REAL>(a.vel, k * T + t);
+    }
+#pragma unroll
+    for (int k = 0; k < 45; ++k) tg.P.a[k] = ld<REAL>(a.P, k * T + t);
+    const double dt = a.dt ? a.dt[t] : a.dt_shared;
+
+    uint32_t s = step_imu9(tg, sc, pr, dt, has_ranging, imu);
+
+    bool fin = true;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        a.pos[k * T + t] = tg.pos[k];
+        st<REAL>(a.vel, k * T + t, tg.vel[k]);
+        fin = fin && isfinite(tg.pos[k]) && isfinite(tg.vel[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 45; ++k) {
+        st<REAL>(a.P, k * T + t, tg.P.a[k]);
+        fin = fin && isfinite(tg.P.a[k]);
+    }
+    const bool waiting = !a.use_init_pos && isnan(tg.pos[0]);
+    if (!fin && !waiting) s |= ST_NONFINITE;
+    a.flags[t] = fl | FL_STARTED;
+    if (a.status) a.status[t] = s;
+}
+
+/* ------------------------------------------------------------------ pose kernel (getPose) */
+struct PoseArgs {
+    int T, model, full;
+    double accel_noise, jolt, dt_ahead;
+    const double *pos_in;
+    const void *vel_in;
+    const void *P;
+    const uint32_t *flags;
+    double *pos, *cov, *vel; /* [3][T], [9][T], [3][T]; any may be null */
+    uint32_t *status;
+};
+
+template <int MODEL, bool SYMM, typename REAL>
+__global__ __launch_bounds__(WAVE) void k_get_pose(const PoseArgs a) {
+    const size_t t = (size_t)blockIdx.x * WAVE + threadIdx.x;
+    if (t >= (size_t)a.T) return;
+    const size_t T = a.T;
+    double pos[3], vel[3] = {0, 0, 0}, cov[9];
+    uint32_t s = 0;
+    if (!(a.flags[t] & FL_STARTED)) {
+        s = ST_NOT_STARTED;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pos[k] = vel[k] = NAN;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) cov[k] = NAN;
+    } else if (MODEL == 6) {
+        Tag6<SYMM> tg;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) tg.pos[k] = a.pos_in[k * T + t];
+#pragma unroll
+        for (int k = 0; k < Cov<6, SYMM>::SZ; ++k) tg.P.a[k] = ld<REAL>(a.P, k * T + t);
+        pose6<SYMM>(tg, a.dt_ahead, a.accel_noise, pos, cov);
+    } else {
+        Tag9 tg;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            tg.pos[k] = a.pos_in[k * T + t];
+            tg.vel[k] = ld<REAL>(a.vel_in, k * T + t);
+        }
+#pragma unroll
+        for (int k = 0; k < 45; ++k) tg.P.a[k] = ld<REAL>(a.P, k * T + t);
+        pose9(tg, a.dt_ahead, a.jolt, pos, vel, cov);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (a.pos) a.pos[k * T + t] = pos[k];
+        if (a.vel) a.vel[k * T + t] = vel[k];
+    }
+    if (a.cov) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) a.cov[k * T + t] = cov[k];
+    }
+    if (a.status) a.status[t] = s;
+}
+
+/* ------------------------------------------------------------------ host side */
+thread_local std::string g_err;
+
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            g_err = std::string(#expr) + ": " + hipGetErrorString(e_);                            \
+            return KFPOS_ERR_HIP;                                                                 \
+        }                                                                                         \
+    } while (0)
+
+} // namespace
+
+struct kfpos_handle {
+    kfpos_config cfg;
+    int n;        /* state dimension */
+    int full;     /* COV_FULL layout: 6-state with ML initialisation (non-symmetric P) */
+    int psz;      /* stored covariance entries per tag */
+    int rsz;      /* sizeof(kfpos_real) */
+    int A;        /* anchors set */
+    bool have_anchors, stepped;
+    double anchors[KFPOS_MAX_ANCHORS * 3];
+    /* device state */
+    double *d_pos = nullptr;
+    void *d_vel = nullptr, *d_P = nullptr, *d_imu_acc = nullptr, *d_imu_cov = nullptr;
+    uint32_t *d_flags = nullptr;
+    /* staging for the host-buffer API */
+    int32_t *d_ranges = nullptr;
+    void *d_err = nullptr, *d_accel = nullptr, *d_cov = nullptr;
+    double *d_dt = nullptr, *d_out = nullptr; /* d_out: [15][T] doubles for pose results */
+    uint32_t *d_status = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+namespace {
+
+size_t lds_bytes(const kfpos_handle *h) { return (size_t)3 * h->cfg.max_anchors * WAVE * sizeof(double); }
+
+void fill_args(const kfpos_handle *h, KArgs &a) {
+    std::memcpy(a.anchors, h->anchors, sizeof(a.anchors));
+    a.T = h->cfg.n_tags;
+    a.A = h->cfg.max_anchors;
+    a.accel_noise = h->cfg.accel_noise;
+    a.jolt = h->cfg.jolt;
+    a.cost_threshold = h->cfg.cost_threshold;
+    a.ignore_worst = h->cfg.ignore_worst;
+    a.top_n = h->cfg.top_n;
+    a.use_init_pos = h->cfg.use_init_pos;
+    a.pos = h->d_pos;
+    a.vel = h->d_vel;
+    a.P = h->d_P;
+    a.flags = h->d_flags;
+    a.imu_acc = h->d_imu_acc;
+    a.imu_cov = h->d_imu_cov;
+    a.ranges = nullptr;
+    a.err = nullptr;
+    a.dt = nullptr;
+    a.dt_shared = 0.0;
+    a.accel = nullptr;
+    a.cov = nullptr;
+    a.mode = MODE_TOA;
+    a.latch = 1;
+    a.status = nullptr;
+}
+
+typedef void (*step_kernel_t)(const KArgs);
+
+step_kernel_t step_kernel(const kfpos_handle *h) {
+    const bool f32 = h->cfg.storage == KFPOS_STORE_F32;
+    if (h->cfg.model == KFPOS_MODEL_TOA) {
+        if (h->full) return f32 ? k_step_toa6<false, float> : k_step_toa6<false, double>;
+        return f32 ? k_step_toa6<true, float> : k_step_toa6<true, double>;
+    }
+    return f32 ? k_step_imu9<float> : k_step_imu9<double>;
+}
+
+int launch_step(kfpos_handle *h, const KArgs &a, hipStream_t s) {
+    const int blocks = (h->cfg.n_tags + WAVE - 1) / WAVE;
+    const size_t lds = (a.mode == MODE_IMU_ONLY) ? 0 : lds_bytes(h);
+    hipLaunchKernelGGL(step_kernel(h), dim3(blocks), dim3(WAVE), lds, s, a);
+    HIPCHK(hipGetLastError());
+    h->stepped = true;
+    return KFPOS_OK;
+}
+
+/* host row-major [T][C] -> staged component-major [C][T] of `esz`-byte elements */
+int stage_in(kfpos_handle *h, void *dst, const void *src, int C, size_t esz) {
+    const size_t T = h->cfg.n_tags;
+    std::vector<unsigned char> tmp(T * C * esz);
+    const unsigned char *s = (const unsigned char *)src;
+    for (size_t t = 0; t < T; ++t)
+        for (int c = 0; c < C; ++c) std::memcpy(&tmp[((size_t)c * T + t) * esz], &s[(t * C + c) * esz], esz);
+    HIPCHK(hipMemcpy(dst, tmp.data(), tmp.size(), hipMemcpyHostToDevice));
+    return KFPOS_OK;
+}
+/* device [C][T] doubles -> host row-major [T][C] */
+int stage_out(kfpos_handle *h, double *dst, const double *dsrc, int C) {
+    const size_t T = h->cfg.n_tags;
+    std::vector<double> tmp(T * C);
+    HIPCHK(hipMemcpy(tmp.data(), dsrc, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (size_t t = 0; t < T; ++t)
+        for (int c = 0; c < C; ++c) dst[t * C + c] = tmp[(size_t)c * T + t];
+    return KFPOS_OK;
+}
+
+int stage_dt(kfpos_handle *h, const double *dt, int32_t dt_len, const double **d_dt, double *shared) {
+    if (!dt || (dt_len != 1 && dt_len != h->cfg.n_tags)) return KFPOS_ERR_ARG;
+    if (dt_len == 1 && h->cfg.n_tags != 1) {
+        *d_dt = nullptr;
+        *shared = dt[0];
+        return KFPOS_OK;
+    }
+    HIPCHK(hipMemcpy(h->d_dt, dt, sizeof(double) * h->cfg.n_tags, hipMemcpyHostToDevice));
+    *d_dt = h->d_dt;
+    *shared = dt[0];
+    return KFPOS_OK;
+}
+
+int fetch_status(kfpos_handle *h, uint32_t *status) {
+    HIPCHK(hipDeviceSynchronize());
+    if (status) HIPCHK(hipMemcpy(status, h->d_status, sizeof(uint32_t) * h->cfg.n_tags, hipMemcpyDeviceToHost));
+    return KFPOS_OK;
+}
+
+/* packed index of the stored covariance entry (i, j) */
+inline int pidx(const kfpos_handle *h, int i, int j) {
+    if (h->full) return i * h->n + j;
+    const int N = h->n;
+    if (i > j) { const int tt = i; i = j; j = tt; }
+    return i * N - i * (i - 1) / 2 + (j - i);
+}
+
+} // namespace
+
+extern "C" {
+
+const char *kfpos_last_error(void) { return g_err.c_str(); }
+const char *kfpos_strerror(int code) {
+    switch (code) {
+    case KFPOS_OK: return "ok";
+    case KFPOS_ERR_ARG: return "invalid argument";
+    case KFPOS_ERR_HIP: return "HIP runtime error";
+    case KFPOS_ERR_NO_DEVICE: return "no usable GPU";
+    case KFPOS_ERR_MODEL: return "call not defined for this model";
+    case KFPOS_ERR_STATE: return "call out of sequence";
+    default: return "unknown error";
+    }
+}
+int kfpos_version(void) { return KFPOS_VERSION; }
+
+int kfpos_create(const kfpos_config *cfg, kfpos_handle **out) {
+    if (!cfg || !out) return KFPOS_ERR_ARG;
+    *out = nullptr;
+    if (cfg->model != KFPOS_MODEL_TOA && cfg->model != KFPOS_MODEL_TOA_IMU) return KFPOS_ERR_ARG;
+    if (cfg->storage != KFPOS_STORE_F64 && cfg->storage != KFPOS_STORE_F32) return KFPOS_ERR_ARG;
+    if (cfg->n_tags < 1 || cfg->max_anchors < 1 || cfg->max_anchors > KFPOS_MAX_ANCHORS) return KFPOS_ERR_ARG;
+    if (cfg->top_n < 0 || (cfg->model == KFPOS_MODEL_TOA_IMU && (cfg->top_n || cfg->ignore_worst)))
+        return KFPOS_ERR_ARG; /* both heuristics exist for the 6-state filter only */
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) {
+        g_err = "no HIP device";
+        return KFPOS_ERR_NO_DEVICE;
+    }
+    HIPCHK(hipSetDevice(cfg->device));
+    kfpos_handle *h = new (std::nothrow) kfpos_handle();
+    if (!h) return KFPOS_ERR_ARG;
+    h->cfg = *cfg;
+    h->n = cfg->model == KFPOS_MODEL_TOA_IMU ? 9 : 6;
+    h->full = (cfg->model == KFPOS_MODEL_TOA && !cfg->use_init_pos) ? 1 : 0;
+    h->psz = h->full ? h->n * h->n : h->n * (h->n + 1) / 2;
+    h->rsz = cfg->storage == KFPOS_STORE_F32 ? 4 : 8;
+    h->A = 0;
+    h->have_anchors = false;
+    h->stepped = false;
+    std::memset(h->anchors, 0, sizeof(h->anchors));
+    const size_t T = cfg->n_tags, A = cfg->max_anchors, r = h->rsz;
+#define ALLOC(ptr, bytes)                                                     \
+    do {                                                                      \
+        hipError_t e_ = hipMalloc((void **)&(ptr), (bytes));                  \
+        if (e_ != hipSuccess) {                                               \
+            g_err = std::string("hipMalloc: ") + hipGetErrorString(e_);       \
+            kfpos_destroy(h);                                                 \
+            return KFPOS_ERR_HIP;                                             \
+        }                                                                     \
+        (void)hipMemset((ptr), 0, (bytes));                                   \
+    } while (0)
+    ALLOC(h->d_pos, 3 * T * sizeof(double));
+    ALLOC(h->d_P, h->psz * T * r);
+    ALLOC(h->d_flags, T * sizeof(uint32_t));
+    if (h->n == 9) {
+        ALLOC(h->d_vel, 3 * T * r);
+        ALLOC(h->d_imu_acc, 3 * T * r);
+        ALLOC(h->d_imu_cov, 6 * T * r);
+        ALLOC(h->d_accel, 3 * T * r);
+        ALLOC(h->d_cov, 9 * T * r);
+    }
+    ALLOC(h->d_ranges, A * T * sizeof(int32_t));
+    ALLOC(h->d_err, A * T * r);
+    ALLOC(h->d_dt, T * sizeof(double));
+    ALLOC(h->d_out, 15 * T * sizeof(double));
+    ALLOC(h->d_status, T * sizeof(uint32_t));
+#undef ALLOC
+    if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
+        g_err = "hipEventCreate failed";
+        kfpos_destroy(h);
+        return KFPOS_ERR_HIP;
+    }
+    if (lds_bytes(h) > 64 * 1024) {
+        hipError_t e_ = hipFuncSetAttribute((const void *)step_kernel(h),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(h));
+        if (e_ != hipSuccess) {
+            g_err = std::string("hipFuncSetAttribute: ") + hipGetErrorString(e_);
+            kfpos_destroy(h);
+            return KFPOS_ERR_HIP;
+        }
+    }
+    /* initial position: fixed start (P0 = 0) or NaN until the ML initialisation */
+    std::vector<double> p0(3 * T);
+    for (size_t t = 0; t < T; ++t)
+        for (int k = 0; k < 3; ++k) p0[(size_t)k * T + t] = cfg->use_init_pos ? cfg->init_pos[k] : NAN;
+    if (hipMemcpy(h->d_pos, p0.data(), p0.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+        g_err = "hipMemcpy(init pos) failed";
+        kfpos_destroy(h);
+        return KFPOS_ERR_HIP;
+    }
+    *out = h;
+    return KFPOS_OK;
+}
+
+int kfpos_destroy(kfpos_handle *h) {
+    if (!h) return KFPOS_ERR_ARG;
+    void *ptrs[] = {h->d_pos, h->d_vel, h->d_P, h->d_imu_acc, h->d_imu_cov, h->d_flags, h->d_ranges,
+                    h->d_err, h->d_accel, h->d_cov, h->d_dt, h->d_out, h->d_status};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    delete h;
+    return KFPOS_OK;
+}
+
+int kfpos_init(kfpos_handle *h) { return h ? KFPOS_OK : KFPOS_ERR_ARG; }
+
+int kfpos_set_anchors(kfpos_handle *h, const double *xyz, const int32_t *ids, int32_t n_anchors) {
+    (void)ids;
+    if (!h || !xyz || n_anchors < 1 || n_anchors > h->cfg.max_anchors) return KFPOS_ERR_ARG;
+    std::memset(h->anchors, 0, sizeof(h->anchors));
+    std::memcpy(h->anchors, xyz, sizeof(double) * 3 * n_anchors);
+    h->A = n_anchors;
+    h->have_anchors = true;
+    return KFPOS_OK;
+}
+
+int kfpos_set_init_positions(kfpos_handle *h, const double *xyz) {
+    if (!h || !xyz) return KFPOS_ERR_ARG;
+    if (!h->cfg.use_init_pos || h->stepped) return KFPOS_ERR_STATE;
+    return stage_in(h, h->d_pos, xyz, 3, sizeof(double));
+}
+
+int kfpos_real_size(const kfpos_handle *h) { return h ? h->rsz : 0; }
+int kfpos_state_dim(const kfpos_handle *h) { return h ? h->n : 0; }
+
+/* ---- device-buffer API ---- */
+int kfpos_step_toa_dev(kfpos_handle *h, const int32_t *range_mm, const void *err_est, const double *dt,
+                       double dt_shared, uint32_t *status, void *stream) {
+    if (!h || !range_mm || !err_est) return KFPOS_ERR_ARG;
+    if (!h->have_anchors) return KFPOS_ERR_STATE;
+    KArgs a;
+    fill_args(h, a);
+    a.ranges = range_mm;
+    a.err = err_est;
+    a.dt = dt;
+    a.dt_shared = dt_shared;
+    a.status = status;
+    a.mode = MODE_TOA;
+    return launch_step(h, a, (hipStream_t)stream);
+}
+
+int kfpos_step_imu_dev(kfpos_handle *h, const void *accel, const void *cov, const double *dt,
+                       double dt_shared, uint32_t *status, void *stream) {
+    if (!h || !accel || !cov) return KFPOS_ERR_ARG;
+    if (h->cfg.model != KFPOS_MODEL_TOA_IMU) return KFPOS_OK; /* KalmanFilterTOA::newIMUMeasurement is empty */
+    KArgs a;
+    fill_args(h, a);
+    a.accel = accel;
+    a.cov = cov;
+    a.dt = dt;
+    a.dt_shared = dt_shared;
+    a.status = status;
+    a.mode = MODE_IMU_ONLY;
+    a.latch = 1;
+    return launch_step(h, a, (hipStream_t)stream);
+}
+
+int kfpos_step_toa_imu_dev(kfpos_handle *h, const int32_t *range_mm, const void *err_est, const void *accel,
+                           const void *cov, int32_t latch, const double *dt, double dt_shared,
+                           uint32_t *status, void *stream) {
+    if (!h || !range_mm || !err_est || !accel || !cov) return KFPOS_ERR_ARG;
+    if (h->cfg.model != KFPOS_MODEL_TOA_IMU) return KFPOS_ERR_MODEL;
+    if (!h->have_anchors) return KFPOS_ERR_STATE;
+    KArgs a;
+    fill_args(h, a);
+    a.ranges = range_mm;
+    a.err = err_est;
+    a.accel = accel;
+    a.cov = cov;
+    a.dt = dt;
+    a.dt_shared = dt_shared;
+    a.status = status;
+    a.mode = MODE_FUSED;
+    a.latch = latch ? 1 : 0;
+    return launch_step(h, a, (hipStream_t)stream);
+}
+
+int kfpos_run_trace_dev(kfpos_handle *h, int32_t n_steps, const int32_t *range_mm, int64_t stride_ranges,
+                        const void *err_est, int64_t stride_err, const void *accel, int64_t stride_accel,
+                        const void *cov, int64_t stride_cov, const double *dt_steps, uint32_t *status,
+                        void *stream) {
+    if (!h || n_steps < 0 || !range_mm || !err_est || !dt_steps) return KFPOS_ERR_ARG;
+    if (accel && (!cov || h->cfg.model != KFPOS_MODEL_TOA_IMU)) return KFPOS_ERR_MODEL;
+    if (!h->have_anchors) return KFPOS_ERR_STATE;
+    KArgs a;
+    fill_args(h, a);
+    a.status = status;
+    a.mode = accel ? MODE_FUSED : MODE_TOA;
+    a.latch = 0;
+    const size_t r = h->rsz;
+    for (int s = 0; s < n_steps; ++s) {
+        a.ranges = range_mm + (size_t)s * stride_ranges;
+        a.err = (const char *)err_est + (size_t)s * stride_err * r;
+        if (accel) {
+            a.accel = (const char *)accel + (size_t)s * stride_accel * r;
+            a.cov = (const char *)cov + (size_t)s * stride_cov * r;
+            a.latch = (s == n_steps - 1) ? 1 : 0; /* leave the last sample latched, as n separate calls would */
+        }
+        a.dt_shared = dt_steps[s];
+        const int rc = launch_step(h, a, (hipStream_t)stream);
+        if (rc != KFPOS_OK) return rc;
+    }
+    return KFPOS_OK;
+}
+
+int kfpos_get_pose_dev(kfpos_handle *h, double dt_ahead, double *pos, double *cov3x3, double *vel,
+                       uint32_t *status, void *stream) {
+    if (!h) return KFPOS_ERR_ARG;
+    PoseArgs a;
+    a.T = h->cfg.n_tags;
+    a.model = h->cfg.model;
+    a.full = h->full;
+    a.accel_noise = h->cfg.accel_noise;
+    a.jolt = h->cfg.jolt;
+    a.dt_ahead = dt_ahead;
+    a.pos_in = h->d_pos;
+    a.vel_in = h->d_vel;
+    a.P = h->d_P;
+    a.flags = h->d_flags;
+    a.pos = pos;
+    a.cov = cov3x3;
+    a.vel = vel;
+    a.status = status;
+    const int blocks = (a.T + WAVE - 1) / WAVE;
+    const bool f32 = h->cfg.storage == KFPOS_STORE_F32;
+    hipStream_t s = (hipStream_t)stream;
+    if (h->cfg.model == KFPOS_MODEL_TOA_IMU) {
+        if (f32) hipLaunchKernelGGL((k_get_pose<9, true, float>), dim3(blocks), dim3(WAVE), 0, s, a);
+        else hipLaunchKernelGGL((k_get_pose<9, true, double>), dim3(blocks), dim3(WAVE), 0, s, a);
+    } else if (h->full) {
+        if (f32) hipLaunchKernelGGL((k_get_pose<6, false, float>), dim3(blocks), dim3(WAVE), 0, s, a);
+        else hipLaunchKernelGGL((k_get_pose<6, false, double>), dim3(blocks), dim3(WAVE), 0, s, a);
+    } else {
+        if (f32) hipLaunchKernelGGL((k_get_pose<6, true, float>), dim3(blocks), dim3(WAVE), 0, s, a);
+        else hipLaunchKernelGGL((k_get_pose<6, true, double>), dim3(blocks), dim3(WAVE), 0, s, a);
+    }
+    HIPCHK(hipGetLastError());
+    return KFPOS_OK;
+}
+
+/* ---- host-buffer API ---- */
+int kfpos_step_toa(kfpos_handle *h, const int32_t *range_mm, const void *err_est, const double *dt,
+                   int32_t dt_len, uint32_t *status) {
+    if (!h || !range_mm || !err_est) return KFPOS_ERR_ARG;
+    if (!h->have_anchors) return KFPOS_ERR_STATE;
+    const double *d_dt;
+    double shared;
+    int rc = stage_dt(h, dt, dt_len, &d_dt, &shared);
+    if (rc) return rc;
+    if ((rc = stage_in(h, h->d_ranges, range_mm, h->cfg.max_anchors, sizeof(int32_t)))) return rc;
+    if ((rc = stage_in(h, h->d_err, err_est, h->cfg.max_anchors, h->rsz))) return rc;
+    if ((rc = kfpos_step_toa_dev(h, h->d_ranges, h->d_err, d_dt, shared, h->d_status, nullptr))) return rc;
+    return fetch_status(h, status);
+}
+
+int kfpos_step_imu(kfpos_handle *h, const void *accel, const void *cov, const double *dt, int32_t dt_len,
+                   uint32_t *status) {
+    if (!h || !accel || !cov) return KFPOS_ERR_ARG;
+    if (h->cfg.model != KFPOS_MODEL_TOA_IMU) {
+        if (status) std::memset(status, 0, sizeof(uint32_t) * h->cfg.n_tags);
+        return KFPOS_OK;
+    }
+    const double *d_dt;
+    double shared;
+    int rc = stage_dt(h, dt, dt_len, &d_dt, &shared);
+    if (rc) return rc;
+    if ((rc = stage_in(h, h->d_accel, accel, 3, h->rsz))) return rc;
+    if ((rc = stage_in(h, h->d_cov, cov, 9, h->rsz))) return rc;
+    if ((rc = kfpos_step_imu_dev(h, h->d_accel, h->d_cov, d_dt, shared, h->d_status, nullptr))) return rc;
+    return fetch_status(h, status);
+}
+
+int kfpos_step_toa_imu(kfpos_handle *h, const int32_t *range_mm, const void *err_est, const void *accel,
+                       const void *cov, const double *dt, int32_t dt_len, uint32_t *status) {
+    if (!h || !range_mm || !err_est || !accel || !cov) return KFPOS_ERR_ARG;
+    if (h->cfg.model != KFPOS_MODEL_TOA_IMU) return KFPOS_ERR_MODEL;
+    if (!h->have_anchors) return KFPOS_ERR_STATE;
+    const double *d_dt;
+    double shared;
+    int rc = stage_dt(h, dt, dt_len, &d_dt, &shared);
+    if (rc) return rc;
+    if ((rc = stage_in(h, h->d_ranges, range_mm, h->cfg.max_anchors, sizeof(int32_t)))) return rc;
+    if ((rc = stage_in(h, h->d_err, err_est, h->cfg.max_anchors, h->rsz))) return rc;
+    if ((rc = stage_in(h, h->d_accel, accel, 3, h->rsz))) return rc;
+    if ((rc = stage_in(h, h->d_cov, cov, 9, h->rsz))) return rc;
+    if ((rc = kfpos_step_toa_imu_dev(h, h->d_ranges, h->d_err, h->d_accel, h->d_cov, 1, d_dt, shared,
+                                     h->d_status, nullptr)))
+        return rc;
+    return fetch_status(h, status);
+}
+
+int kfpos_get_pose(kfpos_handle *h, double dt_ahead, double *pos, double *cov3x3, double *vel,
+                   uint32_t *status) {
+    if (!h) return KFPOS_ERR_ARG;
+    const size_t T = h->cfg.n_tags;
+    double *dp = h->d_out, *dc = h->d_out + 3 * T, *dv = h->d_out + 12 * T;
+    int rc = kfpos_get_pose_dev(h, dt_ahead, dp, dc, dv, h->d_status, nullptr);
+    if (rc) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    if (pos && (rc = stage_out(h, pos, dp, 3))) return rc;
+    if (cov3x3 && (rc = stage_out(h, cov3x3, dc, 9))) return rc;
+    if (vel && (rc = stage_out(h, vel, dv, 3))) return rc;
+    if (status) HIPCHK(hipMemcpy(status, h->d_status, sizeof(uint32_t) * T, hipMemcpyDeviceToHost));
+    return KFPOS_OK;
+}
+
+int kfpos_get_state(kfpos_handle *h, double *x, double *P, uint32_t *flags) {
+    if (!h) return KFPOS_ERR_ARG;
+    HIPCHK(hipDeviceSynchronize());
+    const size_t T = h->cfg.n_tags;
+    const int n = h->n;
+    if (x) {
+        std::vector<double> pos(3 * T);
+        HIPCHK(hipMemcpy(pos.data(), h->d_pos, pos.size() * sizeof(double), hipMemcpyDeviceToHost));
+        std::vector<unsigned char> vel;
+        if (n == 9) {
+            vel.resize(3 * T * h->rsz);
+            HIPCHK(hipMemcpy(vel.data(), h->d_vel, vel.size(), hipMemcpyDeviceToHost));
+        }
+        for (size_t t = 0; t < T; ++t) {
+            for (int k = 0; k < n; ++k) x[t * n + k] = 0.0;
+            for (int k = 0; k < 3; ++k) {
+                x[t * n + k] = pos[(size_t)k * T + t];
+                if (n == 9)
+                    x[t * n + 3 + k] = h->rsz == 4 ? (double)((const float *)vel.data())[(size_t)k * T + t]
+                                                   : ((const double *)vel.data())[(size_t)k * T + t];
+            }
+        }
+    }
+    if (P) {
+        std::vector<unsigned char> buf((size_t)h->psz * T * h->rsz);
+        HIPCHK(hipMemcpy(buf.data(), h->d_P, buf.size(), hipMemcpyDeviceToHost));
+        for (size_t t = 0; t < T; ++t)
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < n; ++j) {
+                    const size_t k = (size_t)pidx(h, i, j) * T + t;
+                    P[(t * n + i) * n + j] = h->rsz == 4 ? (double)((const float *)buf.data())[k]
+                                                          : ((const double *)buf.data())[k];
+                }
+    }
+    if (flags) HIPCHK(hipMemcpy(flags, h->d_flags, sizeof(uint32_t) * T, hipMemcpyDeviceToHost));
+    return KFPOS_OK;
+}
+
+int kfpos_set_state(kfpos_handle *h, const double *x, const double *P, const uint32_t *flags) {
+    if (!h) return KFPOS_ERR_ARG;
+    HIPCHK(hipDeviceSynchronize());
+    const size_t T = h->cfg.n_tags;
+    const int n = h->n;
+    if (x) {
+        std::vector<double> pos(3 * T);
+        std::vector<unsigned char> vel(n == 9 ? 3 * T * h->rsz : 0);
+        for (size_t t = 0; t < T; ++t)
+            for (int k = 0; k < 3; ++k) {
+                pos[(size_t)k * T + t] = x[t * n + k];
+                if (n == 9) {
+                    if (h->rsz == 4) ((float *)vel.data())[(size_t)k * T + t] = (float)x[t * n + 3 + k];
+                    else ((double *)vel.data())[(size_t)k * T + t] = x[t * n + 3 + k];
+                }
+            }
+        HIPCHK(hipMemcpy(h->d_pos, pos.data(), pos.size() * sizeof(double), hipMemcpyHostToDevice));
+        if (n == 9) HIPCHK(hipMemcpy(h->d_vel, vel.data(), vel.size(), hipMemcpyHostToDevice));
+    }
+    if (P) {
+        std::vector<unsigned char> buf((size_t)h->psz * T * h->rsz);
+        for (size_t t = 0; t < T; ++t)
+            for (int i = 0; i < n; ++i)
+                for (int j = h->full ? 0 : i; j < n; ++j) {
+                    const size_t k = (size_t)pidx(h, i, j) * T + t;
+                    const double v = P[(t * n + i) * n + j];
+                    if (h->rsz == 4) ((float *)buf.data())[k] = (float)v;
+                    else ((double *)buf.data())[k] = v;
+                }
+        HIPCHK(hipMemcpy(h->d_P, buf.data(), buf.size(), hipMemcpyHostToDevice));
+    }
+    if (flags) HIPCHK(hipMemcpy(h->d_flags, flags, sizeof(uint32_t) * T, hipMemcpyHostToDevice));
+    h->stepped = true;
+    return KFPOS_OK;
+}
+
+int kfpos_timing_begin(kfpos_handle *h, void *stream) {
+    if (!h) return KFPOS_ERR_ARG;
+    HIPCHK(hipEventRecord(h->ev0, (hipStream_t)stream));
+    return KFPOS_OK;
+}
+int kfpos_timing_end(kfpos_handle *h, void *stream, float *elapsed_ms) {
+    if (!h || !elapsed_ms) return KFPOS_ERR_ARG;
+    HIPCHK(hipEventRecord(h->ev1, (hipStream_t)stream));
+    HIPCHK(hipEventSynchronize(h->ev1));
+    HIPCHK(hipEventElapsedTime(elapsed_ms, h->ev0, h->ev1));
+    return KFPOS_OK;
+}
+
+} // extern "C"

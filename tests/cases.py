@@ -1,0 +1,114 @@
+"""Shared parity cases: the same seeded traces drive the oracle, the host emulation of the kernel
+body (CPU tests) and the HIP library through the C ABI (GPU tests).
+
+Edge cases folded into every trace, mirroring what the reference code paths distinguish:
+  - an anchor that drops out for an epoch (range <= 0, Posgenerator.cpp:483)
+  - epochs with fewer than 4 ranges (ML returns its seed, MLLocation.cpp:158-161)
+  - an epoch with no range at all
+  - NLOS-like positive range bias (what the ignore-worst / top-N heuristics react to)
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from roskfpos_amd.synth import Workload
+
+MODEL_TOA, MODEL_TOA_IMU = 0, 1
+
+
+class Case:
+    def __init__(self, name, model, A, fixed=True, ignore_worst=False, top_n=0, outlier=False,
+                 T=48, S=80, imu_every=1, separate_imu=False, cov_full=False):
+        self.name, self.model, self.A, self.fixed = name, model, A, fixed
+        self.ignore_worst, self.top_n, self.outlier = ignore_worst, top_n, outlier
+        self.T, self.S = T, S
+        self.imu_every = imu_every        # a fresh IMU sample every k-th epoch (others re-fuse the latch)
+        self.separate_imu = separate_imu  # IMU samples arrive as their own step with dt > 0
+        self.cov_full = cov_full          # IMU covariance with off-diagonal terms
+
+    def workload(self):
+        return Workload(self.T, self.A)
+
+    def epoch(self, w, s):
+        r = w.ranges_mm(s)
+        if s % 7 == 3:
+            r[:, 1] = -1
+        if s % 11 == 5:
+            r[::3, 2:] = 0
+        if s % 23 == 9:
+            r[1::4, :] = 0
+        if self.outlier:
+            r[::5, 3] += 800
+        return r
+
+    def accel_cov(self, w):
+        c = w.accel_cov()
+        if self.cov_full:
+            m = np.array([[0.010, 0.002, -0.001], [0.002, 0.012, 0.003], [-0.001, 0.003, 0.009]])
+            c = np.tile(m.reshape(1, 9), (self.T, 1))
+        return c
+
+
+CASES = [
+    Case("toa6_A8_fixed", MODEL_TOA, 8),
+    Case("toa6_A4_fixed", MODEL_TOA, 4),
+    Case("toa6_A16_fixed", MODEL_TOA, 16),
+    Case("toa6_A8_mlinit", MODEL_TOA, 8, fixed=False),
+    Case("toa6_A8_ignoreworst", MODEL_TOA, 8, ignore_worst=True, outlier=True),
+    Case("toa6_A16_top2", MODEL_TOA, 16, top_n=2, outlier=True),
+    Case("imu9_A8_fixed", MODEL_TOA_IMU, 8),
+    Case("imu9_A8_mlinit", MODEL_TOA_IMU, 8, fixed=False),
+    Case("imu9_A8_latched", MODEL_TOA_IMU, 8, imu_every=3, cov_full=True),
+    Case("imu9_A8_separate", MODEL_TOA_IMU, 8, separate_imu=True),
+]
+CASE_BY_NAME = {c.name: c for c in CASES}
+
+
+def drive(case, make_filter, real=np.float64, steps=None, record=False):
+    """Run `case` through any object with step_toa / step_imu / step_toa_imu-like methods.
+
+    make_filter(case, workload, init_pos) -> object with
+        step_toa(r, err, dt) -> status, step_imu(a, cov, dt) -> status,
+        fused(r, err, a, cov, dt) -> status   (latch + ranging epoch),
+        positions() -> (T, 3)
+    Measurement arrays are rounded to `real` first so that every implementation sees identical
+    values (the f32-storage GPU path reads float32 measurements).
+    """
+    w = case.workload()
+    init = w.init_positions() if case.fixed else None
+    f = make_filter(case, w, init)
+    err = w.err_est().astype(real).astype(np.float64)
+    cov = case.accel_cov(w).astype(real).astype(np.float64)
+    S = steps or case.S
+    pos_hist, st_hist = [], []
+    for s in range(S):
+        r = case.epoch(w, s)
+        dt = w.dt_of(s)
+        if case.model == MODEL_TOA_IMU:
+            a = w.accel(s).astype(real).astype(np.float64)
+            fresh = (s % case.imu_every) == 0
+            if case.separate_imu:
+                f.step_imu(a, cov, 0.4 * dt)
+                st = f.step_toa(r, err, 0.6 * dt)
+            elif fresh:
+                st = f.fused(r, err, a, cov, dt)
+            else:
+                st = f.step_toa(r, err, dt)
+        else:
+            st = f.step_toa(r, err, dt)
+        if record:
+            pos_hist.append(f.positions().copy())
+            st_hist.append(np.asarray(st).copy())
+    if record:
+        return f, np.stack(pos_hist), np.stack(st_hist)
+    return f
+
+
+def rms_and_max(pa, pb):
+    """RMS / max position difference over entries that are finite in the oracle."""
+    ok = np.isfinite(pb).all(-1)
+    same_nan = np.array_equal(np.isfinite(pa).all(-1), ok)
+    d = pa[ok] - pb[ok]
+    if d.size == 0:
+        return 0.0, 0.0, same_nan
+    return float(np.sqrt((d ** 2).sum(-1).mean())), float(np.abs(d).max()), same_nan

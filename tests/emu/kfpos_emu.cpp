@@ -1,0 +1,164 @@
+/*
+ * kfpos_emu.cpp -- host emulation of the per-lane kernel body (roskfpos_amd/csrc/kfpos_core.h).
+ *
+ * TEST INFRASTRUCTURE ONLY. There is no GPU in the development container, so the CPU test
+ * suite compiles the exact per-tag arithmetic the HIP kernels run (same header, same
+ * templates) with g++ and checks it against the oracle. It is never loaded by the product:
+ * roskfpos_amd fails loudly when libkfpos_hip.so or a GPU is missing. The emulation keeps
+ * the kernel's data model: integer-mm ranges in, per-lane scratch (stride 1 instead of the
+ * LDS stride), packed covariance.
+ */
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../roskfpos_amd/csrc/kfpos_core.h"
+
+using namespace kfpos;
+
+struct kfe_bank {
+    int model, T, A, full; /* full: COV_FULL layout (6-state ML-init mode) */
+    Params pr;
+    std::vector<double> anchors;
+    std::vector<Tag6<true>> t6s;
+    std::vector<Tag6<false>> t6f;
+    std::vector<Tag9> t9;
+    std::vector<Imu> imu;
+    std::vector<uint32_t> flags;
+};
+
+extern "C" {
+
+kfe_bank *kfe_create(int model, int n_tags, int n_anchors, const double *anchors, double accel_noise,
+                     double jolt, int ignore_worst, double cost_threshold, int top_n, int use_init_pos,
+                     const double *init_pos) {
+    kfe_bank *b = new kfe_bank();
+    b->model = model;
+    b->T = n_tags;
+    b->A = n_anchors;
+    b->full = (model == 0 && !use_init_pos) ? 1 : 0;
+    b->anchors.assign(anchors, anchors + 3 * n_anchors);
+    b->pr.anchors = b->anchors.data();
+    b->pr.n_anchors = n_anchors;
+    b->pr.accel_noise = accel_noise;
+    b->pr.jolt = jolt;
+    b->pr.cost_threshold = cost_threshold;
+    b->pr.ignore_worst = ignore_worst;
+    b->pr.top_n = top_n;
+    b->pr.use_init_pos = use_init_pos;
+    b->flags.assign(n_tags, 0u);
+    auto ip = [&](int t, int k) { return use_init_pos ? (init_pos ? init_pos[3 * t + k] : 0.0) : NAN; };
+    if (model == 0 && !b->full) {
+        b->t6s.resize(n_tags);
+        for (int t = 0; t < n_tags; ++t) {
+            std::memset(&b->t6s[t], 0, sizeof(Tag6<true>));
+            for (int k = 0; k < 3; ++k) b->t6s[t].pos[k] = ip(t, k);
+        }
+    } else if (model == 0) {
+        b->t6f.resize(n_tags);
+        for (int t = 0; t < n_tags; ++t) {
+            std::memset(&b->t6f[t], 0, sizeof(Tag6<false>));
+            for (int k = 0; k < 3; ++k) b->t6f[t].pos[k] = ip(t, k);
+        }
+    } else {
+        b->t9.resize(n_tags);
+        b->imu.resize(n_tags);
+        for (int t = 0; t < n_tags; ++t) {
+            std::memset(&b->t9[t], 0, sizeof(Tag9));
+            std::memset(&b->imu[t], 0, sizeof(Imu));
+            for (int k = 0; k < 3; ++k) b->t9[t].pos[k] = ip(t, k);
+        }
+    }
+    return b;
+}
+void kfe_destroy(kfe_bank *b) { delete b; }
+
+static void fill_scratch(const kfe_bank *b, const int32_t *mm, const double *err, std::vector<double> &buf,
+                         Scratch &sc) {
+    const int A = b->A;
+    buf.assign(3 * A, 0.0);
+    sc.r = buf.data();
+    sc.e = buf.data() + A;
+    sc.w = buf.data() + 2 * A;
+    sc.stride = 1;
+    for (int a = 0; a < A; ++a) {
+        sc.r[a] = mm[a] > 0 ? (double)mm[a] / 1000 : 0.0; /* Posgenerator.cpp:483-484 */
+        sc.e[a] = err[a];
+    }
+}
+
+void kfe_step_toa(kfe_bank *b, const int32_t *range_mm, const double *err_est, const double *dt, int dt_len,
+                  uint32_t *status) {
+    std::vector<double> buf;
+    Scratch sc;
+    for (int t = 0; t < b->T; ++t) {
+        fill_scratch(b, range_mm + (size_t)t * b->A, err_est + (size_t)t * b->A, buf, sc);
+        const double lag = dt[dt_len > 1 ? t : 0];
+        uint32_t st;
+        if (b->model == 0 && !b->full) st = step_toa6(b->t6s[t], sc, b->pr, lag);
+        else if (b->model == 0) st = step_toa6(b->t6f[t], sc, b->pr, lag);
+        else st = step_imu9(b->t9[t], sc, b->pr, lag, true, b->imu[t]);
+        b->flags[t] |= FL_STARTED;
+        if (status) status[t] = st;
+    }
+}
+
+void kfe_latch_imu(kfe_bank *b, const double *accel, const double *cov) {
+    if (b->model != 1) return;
+    for (int t = 0; t < b->T; ++t) {
+        Imu &im = b->imu[t];
+        im.has = true;
+        for (int k = 0; k < 3; ++k) im.acc[k] = accel[3 * t + k];
+        imu_whitener(cov + 9 * (size_t)t, im.ci);
+        b->flags[t] |= FL_HAS_IMU;
+    }
+}
+
+void kfe_step_imu(kfe_bank *b, const double *accel, const double *cov, const double *dt, int dt_len,
+                  uint32_t *status) {
+    if (b->model != 1) return;
+    kfe_latch_imu(b, accel, cov);
+    Scratch sc{nullptr, nullptr, nullptr, 1};
+    for (int t = 0; t < b->T; ++t) {
+        uint32_t st = step_imu9(b->t9[t], sc, b->pr, dt[dt_len > 1 ? t : 0], false, b->imu[t]);
+        b->flags[t] |= FL_STARTED;
+        if (status) status[t] = st;
+    }
+}
+
+/* x: T*n ([pos, vel(, 0)]), P: T*n*n full row-major */
+void kfe_get_state(const kfe_bank *b, double *x, double *P) {
+    const int n = b->model == 1 ? 9 : 6;
+    for (int t = 0; t < b->T; ++t) {
+        double *xt = x + (size_t)t * n, *Pt = P + (size_t)t * n * n;
+        for (int k = 0; k < n; ++k) xt[k] = 0.0;
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) {
+                if (b->model == 1) Pt[i * n + j] = b->t9[t].P(i, j);
+                else if (b->full) Pt[i * n + j] = b->t6f[t].P(i, j);
+                else Pt[i * n + j] = b->t6s[t].P(i, j);
+            }
+        for (int k = 0; k < 3; ++k) {
+            if (b->model == 1) { xt[k] = b->t9[t].pos[k]; xt[3 + k] = b->t9[t].vel[k]; }
+            else xt[k] = b->full ? b->t6f[t].pos[k] : b->t6s[t].pos[k];
+        }
+    }
+}
+
+void kfe_get_pose(const kfe_bank *b, double dt_ahead, double *pos, double *cov3x3, double *vel) {
+    for (int t = 0; t < b->T; ++t) {
+        double v[3] = {0, 0, 0};
+        if (!(b->flags[t] & FL_STARTED)) {
+            for (int k = 0; k < 3; ++k) { pos[3 * t + k] = NAN; vel[3 * t + k] = NAN; }
+            for (int k = 0; k < 9; ++k) cov3x3[9 * t + k] = NAN;
+            continue;
+        }
+        if (b->model == 1) pose9(b->t9[t], dt_ahead, b->pr.jolt, pos + 3 * t, v, cov3x3 + 9 * t);
+        else if (b->full) pose6(b->t6f[t], dt_ahead, b->pr.accel_noise, pos + 3 * t, cov3x3 + 9 * t);
+        else pose6(b->t6s[t], dt_ahead, b->pr.accel_noise, pos + 3 * t, cov3x3 + 9 * t);
+        for (int k = 0; k < 3; ++k) vel[3 * t + k] = v[k];
+    }
+}
+
+} // extern "C"
