@@ -39,9 +39,13 @@ extern "C" {
 #define KFPOS_MODEL_TOA     0 /* ALGORITHM_KF_TOA     -> KalmanFilterTOA, 6 states p,v */
 #define KFPOS_MODEL_TOA_IMU 1 /* ALGORITHM_KF_TOA_IMU -> KalmanFilterTOAIMU, 9 states p,v,a (3-token repair) */
 
-/* ---- storage precision of covariance / velocity / measurements in HBM; arithmetic is always f64 ---- */
-#define KFPOS_STORE_F64 0 /* kfpos_real = double */
-#define KFPOS_STORE_F32 1 /* kfpos_real = float (positions stay double; ranges are exact integer mm) */
+/* ---- storage precision of the covariance and of the measurements in HBM; arithmetic is always f64 ----
+ * Positions and velocities are kept as double in both modes, ranges are exact integer mm. F32 rounds the
+ * covariance to 24 bits between epochs: <= 1e-6 m RMS on the BASELINE traces (measured 5.6e-7 m), but the
+ * 9-state filter amplifies that rounding in degraded epochs (< 4 ranges); F64 is exact. */
+#define KFPOS_STORE_F64   0 /* covariance double, measurements (kfpos_real) double */
+#define KFPOS_STORE_F32   1 /* covariance float,  measurements (kfpos_real) float */
+#define KFPOS_STORE_MIXED 2 /* covariance double, measurements (kfpos_real) float: exact filter state, compact inputs */
 
 #define KFPOS_MAX_ANCHORS 64 /* MAX_NUM_ANCS, Posgenerator.h:74 */
 

@@ -74,7 +74,7 @@ def ml_estimate(meas, seed):
     n = len(meas)
     if n < 4:
         return p, None, 0
-    cost, new_cost, it = 1e20, 1.0, 0
+    cost, new_cost, it = np.float64(1e20), np.float64(1.0), 0
     with np.errstate(all="ignore"):
         while abs(cost - new_cost) / cost > 1e-3 and it < 10000:
             it += 1
@@ -93,7 +93,7 @@ def ml_estimate(meas, seed):
                     Hs[l, k] += t
             p = arma_solve_equilibrate(Hs, Hs @ p - g)
             d = distances(p, meas)
-            new_cost = sum((meas[i][0] - d[i]) ** 2 / meas[i][1] for i in range(n))
+            new_cost = np.float64(sum((meas[i][0] - d[i]) ** 2 / meas[i][1] for i in range(n)))
         d = distances(p, meas)
         rng_err = ml_error(meas, p)
         J = np.array([[(p[0] - m[2]) / d[i], (p[1] - m[3]) / d[i], (p[2] - m[4]) / d[i]]
@@ -151,7 +151,7 @@ def iekf_step(n, pred, Pm, has_ranging, meas_all, ignored, has_imu, imu_acc, imu
             R[nr:, nr:] = np.asarray(imu_cov).reshape(3, 3)
         Ri, Pp = arma_inv(R), arma_pinv(Pm)
         H, K = np.zeros((m, n)), np.zeros((n, m))
-        cost, gains = 1e20, 0
+        cost, gains = np.float64(1e20), 0
         for _ in range(max_steps):
             h = np.zeros(m)
             d = distances(x[:3], rm)
@@ -159,7 +159,7 @@ def iekf_step(n, pred, Pm, has_ranging, meas_all, ignored, has_imu, imu_acc, imu
             if has_imu:
                 h[nr:] = x[6:9]
             y, dl = z - h, pred - x
-            new_cost = float(y @ Ri @ y + dl @ Pp @ dl)
+            new_cost = np.float64(y @ Ri @ y + dl @ Pp @ dl)
             if abs(cost - new_cost) / cost < tol:
                 break
             cost = new_cost

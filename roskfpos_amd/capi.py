@@ -16,7 +16,7 @@ _DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_DIR, "csrc", "libkfpos_hip.so")
 
 MODEL_TOA, MODEL_TOA_IMU = 0, 1
-STORE_F64, STORE_F32 = 0, 1
+STORE_F64, STORE_F32, STORE_MIXED = 0, 1, 2
 MAX_ANCHORS = 64
 ST_UPDATE_SKIPPED, ST_ML_FALLBACK, ST_FEW_RANGES, ST_ML_INIT, ST_NOT_STARTED, ST_NONFINITE = 1, 2, 4, 8, 16, 32
 
@@ -51,6 +51,13 @@ def load():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise KfposError(f"{LIB_PATH} is not built: run __graft_entry__.build() (hipcc --offload-arch=gfx950)")
+    try:
+        # PyTorch wheels bundle their own libamdhip64.so.7; whichever copy is loaded first serves the whole
+        # process. If torch is going to share this process (device tensors, RCCL) its copy has to be that
+        # one, otherwise torch.cuda later reports "No HIP GPUs are available".
+        import torch  # noqa: F401
+    except Exception:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, i32, f64 = C.c_void_p, C.c_int32, C.c_double
     L.kfpos_create.argtypes = [C.POINTER(_Config), C.POINTER(vp)]
@@ -101,7 +108,7 @@ class KfposBank:
         anchors = np.ascontiguousarray(anchors, dtype=np.float64)
         self.T, self.A = int(n_tags), int(max_anchors or anchors.shape[0])
         self.model, self.storage = model, storage
-        self.real = np.float32 if storage == STORE_F32 else np.float64
+        self.real = np.float64 if storage == STORE_F64 else np.float32  # kfpos_real: measurement element type
         cfg = _Config()
         cfg.model, cfg.n_tags, cfg.max_anchors, cfg.storage = model, self.T, self.A, storage
         cfg.accel_noise, cfg.jolt = accel_noise, jolt

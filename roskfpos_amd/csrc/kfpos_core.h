@@ -150,7 +150,7 @@ struct Scratch {
     KFPOS_HD void setW(int a, double v) const { w[a * stride] = v; }
 };
 KFPOS_HD inline bool used(const Scratch &sc, int a, uint64_t drop) {
-    return sc.R(a) > 0.0 && !((drop >> a) & 1ull);
+    return !((drop >> a) & 1ull) && sc.R(a) > 0.0;
 }
 KFPOS_HD inline int count_used(const Scratch &sc, int A, uint64_t drop) {
     int n = 0;

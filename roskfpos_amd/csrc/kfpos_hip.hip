@@ -51,7 +51,7 @@ struct KArgs {
     int ignore_worst, top_n, use_init_pos;
     /* persistent state, component-major */
     double *pos;      /* [3][T] */
-    void *vel;        /* [3][T] real (9-state) */
+    double *vel;      /* [3][T] (9-state; always f64: the 9-state filter amplifies velocity rounding) */
     void *P;          /* [SZ][T] real */
     uint32_t *flags;  /* [T] */
     void *imu_acc;    /* [3][T] real, latched sample (9-state) */
@@ -86,7 +86,7 @@ __device__ inline Params make_params(const KArgs &a) {
 }
 
 /* epoch -> per-lane LDS scratch */
-template <typename REAL>
+template <typename MREAL>
 __device__ inline Scratch stage_epoch(const KArgs &a, double *lds, int lane, size_t t) {
     Scratch sc;
     sc.r = lds + lane;
@@ -96,13 +96,13 @@ __device__ inline Scratch stage_epoch(const KArgs &a, double *lds, int lane, siz
     for (int k = 0; k < a.A; ++k) {
         const int32_t mm = a.ranges[(size_t)k * a.T + t];
         sc.r[k * WAVE] = mm > 0 ? (double)mm / 1000 : 0.0; /* Posgenerator.cpp:483-484 */
-        sc.e[k * WAVE] = ld<REAL>(a.err, (size_t)k * a.T + t);
+        sc.e[k * WAVE] = ld<MREAL>(a.err, (size_t)k * a.T + t);
     }
     return sc;
 }
 
 /* ------------------------------------------------------------------ 6-state step kernel */
-template <bool SYMM, typename REAL>
+template <bool SYMM, typename REAL, typename MREAL>
 __global__ __launch_bounds__(WAVE) void k_step_toa6(const KArgs a) {
     extern __shared__ double lds[];
     const int lane = threadIdx.x;
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(WAVE) void k_step_toa6(const KArgs a) {
     if (t >= (size_t)a.T) return;
     const size_t T = a.T;
     const Params pr = make_params(a);
-    const Scratch sc = stage_epoch<REAL>(a, lds, lane, t);
+    const Scratch sc = stage_epoch<MREAL>(a, lds, lane, t);
 
     Tag6<SYMM> tg;
 #pragma unroll
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(WAVE) void k_step_toa6(const KArgs a) {
 }
 
 /* ------------------------------------------------------------------ 9-state step kernel */
-template <typename REAL>
+template <typename REAL, typename MREAL>
 __global__ __launch_bounds__(WAVE) void k_step_imu9(const KArgs a) {
     extern __shared__ double lds[];
     const int lane = threadIdx.x;
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(WAVE) void k_step_imu9(const KArgs a) {
     const Params pr = make_params(a);
     const bool has_ranging = a.mode != MODE_IMU_ONLY;
     Scratch sc{nullptr, nullptr, nullptr, WAVE};
-    if (has_ranging) sc = stage_epoch<REAL>(a, lds, lane, t);
+    if (has_ranging) sc = stage_epoch<MREAL>(a, lds, lane, t);
 
     uint32_t fl = a.flags[t];
     Imu imu;
@@ -158,30 +158,30 @@ __global__ __launch_bounds__(WAVE) void k_step_imu9(const KArgs a) {
     if (a.mode != MODE_TOA) { /* fresh sample: newIMUMeasurement latches it (KalmanFilterTOAIMU.cpp:78-89) */
         imu.has = true;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) imu.acc[k] = ld<REAL>(a.accel, k * T + t);
+        for (int k = 0; k < 3; ++k) imu.acc[k] = ld<MREAL>(a.accel, k * T + t);
 #pragma unroll
-        for (int k = 0; k < 9; ++k) cv[k] = ld<REAL>(a.cov, k * T + t);
+        for (int k = 0; k < 9; ++k) cv[k] = ld<MREAL>(a.cov, k * T + t);
         if (a.latch) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) st<REAL>(a.imu_acc, k * T + t, imu.acc[k]);
-            st<REAL>(a.imu_cov, 0 * T + t, cv[0]);
-            st<REAL>(a.imu_cov, 1 * T + t, cv[3]);
-            st<REAL>(a.imu_cov, 2 * T + t, cv[4]);
-            st<REAL>(a.imu_cov, 3 * T + t, cv[6]);
-            st<REAL>(a.imu_cov, 4 * T + t, cv[7]);
-            st<REAL>(a.imu_cov, 5 * T + t, cv[8]);
+            for (int k = 0; k < 3; ++k) st<MREAL>(a.imu_acc, k * T + t, imu.acc[k]);
+            st<MREAL>(a.imu_cov, 0 * T + t, cv[0]);
+            st<MREAL>(a.imu_cov, 1 * T + t, cv[3]);
+            st<MREAL>(a.imu_cov, 2 * T + t, cv[4]);
+            st<MREAL>(a.imu_cov, 3 * T + t, cv[6]);
+            st<MREAL>(a.imu_cov, 4 * T + t, cv[7]);
+            st<MREAL>(a.imu_cov, 5 * T + t, cv[8]);
             fl |= FL_HAS_IMU;
         }
     } else if (fl & FL_HAS_IMU) { /* re-fuse the latched sample (KalmanFilterTOAIMU.cpp:68-72) */
         imu.has = true;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) imu.acc[k] = ld<REAL>(a.imu_acc, k * T + t);
-        cv[0] = ld<REAL>(a.imu_cov, 0 * T + t);
-        cv[3] = ld<REAL>(a.imu_cov, 1 * T + t);
-        cv[4] = ld<REAL>(a.imu_cov, 2 * T + t);
-        cv[6] = ld<REAL>(a.imu_cov, 3 * T + t);
-        cv[7] = ld<REAL>(a.imu_cov, 4 * T + t);
-        cv[8] = ld<REAL>(a.imu_cov, 5 * T + t);
+        for (int k = 0; k < 3; ++k) imu.acc[k] = ld<MREAL>(a.imu_acc, k * T + t);
+        cv[0] = ld<MREAL>(a.imu_cov, 0 * T + t);
+        cv[3] = ld<MREAL>(a.imu_cov, 1 * T + t);
+        cv[4] = ld<MREAL>(a.imu_cov, 2 * T + t);
+        cv[6] = ld<MREAL>(a.imu_cov, 3 * T + t);
+        cv[7] = ld<MREAL>(a.imu_cov, 4 * T + t);
+        cv[8] = ld<MREAL>(a.imu_cov, 5 * T + t);
     }
     if (imu.has) imu_whitener(cv, imu.ci);
 
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(WAVE) void k_step_imu9(const KArgs a) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         tg.pos[k] = a.pos[k * T + t];
-        tg.vel[k] = ld<REAL>(a.vel, k * T + t);
+        tg.vel[k] = a.vel[k * T + t];
     }
 #pragma unroll
     for (int k = 0; k < 45; ++k) tg.P.a[k] = ld<REAL>(a.P, k * T + t);
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(WAVE) void k_step_imu9(const KArgs a) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         a.pos[k * T + t] = tg.pos[k];
-        st<REAL>(a.vel, k * T + t, tg.vel[k]);
+        a.vel[k * T + t] = tg.vel[k];
         fin = fin && isfinite(tg.pos[k]) && isfinite(tg.vel[k]);
     }
 #pragma unroll
@@ -220,7 +220,7 @@ struct PoseArgs {
     int T, model, full;
     double accel_noise, jolt, dt_ahead;
     const double *pos_in;
-    const void *vel_in;
+    const double *vel_in;
     const void *P;
     const uint32_t *flags;
     double *pos, *cov, *vel; /* [3][T], [9][T], [3][T]; any may be null */
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(WAVE) void k_get_pose(const PoseArgs a) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             tg.pos[k] = a.pos_in[k * T + t];
-            tg.vel[k] = ld<REAL>(a.vel_in, k * T + t);
+            tg.vel[k] = a.vel_in[k * T + t];
         }
 #pragma unroll
         for (int k = 0; k < 45; ++k) tg.P.a[k] = ld<REAL>(a.P, k * T + t);
@@ -289,13 +289,15 @@ struct kfpos_handle {
     int n;        /* state dimension */
     int full;     /* COV_FULL layout: 6-state with ML initialisation (non-symmetric P) */
     int psz;      /* stored covariance entries per tag */
-    int rsz;      /* sizeof(kfpos_real) */
+    int rsz;      /* bytes per stored covariance entry */
+    int msz;      /* sizeof(kfpos_real): bytes per measurement element */
     int A;        /* anchors set */
     bool have_anchors, stepped;
     double anchors[KFPOS_MAX_ANCHORS * 3];
     /* device state */
     double *d_pos = nullptr;
-    void *d_vel = nullptr, *d_P = nullptr, *d_imu_acc = nullptr, *d_imu_cov = nullptr;
+    double *d_vel = nullptr;
+    void *d_P = nullptr, *d_imu_acc = nullptr, *d_imu_cov = nullptr;
     uint32_t *d_flags = nullptr;
     /* staging for the host-buffer API */
     int32_t *d_ranges = nullptr;
@@ -339,12 +341,16 @@ void fill_args(const kfpos_handle *h, KArgs &a) {
 typedef void (*step_kernel_t)(const KArgs);
 
 step_kernel_t step_kernel(const kfpos_handle *h) {
-    const bool f32 = h->cfg.storage == KFPOS_STORE_F32;
+    const int st = h->cfg.storage;
     if (h->cfg.model == KFPOS_MODEL_TOA) {
-        if (h->full) return f32 ? k_step_toa6<false, float> : k_step_toa6<false, double>;
-        return f32 ? k_step_toa6<true, float> : k_step_toa6<true, double>;
+        if (h->full)
+            return st == KFPOS_STORE_F32 ? k_step_toa6<false, float, float>
+                 : st == KFPOS_STORE_MIXED ? k_step_toa6<false, double, float> : k_step_toa6<false, double, double>;
+        return st == KFPOS_STORE_F32 ? k_step_toa6<true, float, float>
+             : st == KFPOS_STORE_MIXED ? k_step_toa6<true, double, float> : k_step_toa6<true, double, double>;
     }
-    return f32 ? k_step_imu9<float> : k_step_imu9<double>;
+    return st == KFPOS_STORE_F32 ? k_step_imu9<float, float>
+         : st == KFPOS_STORE_MIXED ? k_step_imu9<double, float> : k_step_imu9<double, double>;
 }
 
 int launch_step(kfpos_handle *h, const KArgs &a, hipStream_t s) {
@@ -425,7 +431,8 @@ int kfpos_create(const kfpos_config *cfg, kfpos_handle **out) {
     if (!cfg || !out) return KFPOS_ERR_ARG;
     *out = nullptr;
     if (cfg->model != KFPOS_MODEL_TOA && cfg->model != KFPOS_MODEL_TOA_IMU) return KFPOS_ERR_ARG;
-    if (cfg->storage != KFPOS_STORE_F64 && cfg->storage != KFPOS_STORE_F32) return KFPOS_ERR_ARG;
+    if (cfg->storage != KFPOS_STORE_F64 && cfg->storage != KFPOS_STORE_F32 && cfg->storage != KFPOS_STORE_MIXED)
+        return KFPOS_ERR_ARG;
     if (cfg->n_tags < 1 || cfg->max_anchors < 1 || cfg->max_anchors > KFPOS_MAX_ANCHORS) return KFPOS_ERR_ARG;
     if (cfg->top_n < 0 || (cfg->model == KFPOS_MODEL_TOA_IMU && (cfg->top_n || cfg->ignore_worst)))
         return KFPOS_ERR_ARG; /* both heuristics exist for the 6-state filter only */
@@ -442,11 +449,12 @@ int kfpos_create(const kfpos_config *cfg, kfpos_handle **out) {
     h->full = (cfg->model == KFPOS_MODEL_TOA && !cfg->use_init_pos) ? 1 : 0;
     h->psz = h->full ? h->n * h->n : h->n * (h->n + 1) / 2;
     h->rsz = cfg->storage == KFPOS_STORE_F32 ? 4 : 8;
+    h->msz = cfg->storage == KFPOS_STORE_F64 ? 8 : 4;
     h->A = 0;
     h->have_anchors = false;
     h->stepped = false;
     std::memset(h->anchors, 0, sizeof(h->anchors));
-    const size_t T = cfg->n_tags, A = cfg->max_anchors, r = h->rsz;
+    const size_t T = cfg->n_tags, A = cfg->max_anchors, r = h->rsz, m = h->msz;
 #define ALLOC(ptr, bytes)                                                     \
     do {                                                                      \
         hipError_t e_ = hipMalloc((void **)&(ptr), (bytes));                  \
@@ -461,14 +469,14 @@ int kfpos_create(const kfpos_config *cfg, kfpos_handle **out) {
     ALLOC(h->d_P, h->psz * T * r);
     ALLOC(h->d_flags, T * sizeof(uint32_t));
     if (h->n == 9) {
-        ALLOC(h->d_vel, 3 * T * r);
-        ALLOC(h->d_imu_acc, 3 * T * r);
-        ALLOC(h->d_imu_cov, 6 * T * r);
-        ALLOC(h->d_accel, 3 * T * r);
-        ALLOC(h->d_cov, 9 * T * r);
+        ALLOC(h->d_vel, 3 * T * sizeof(double));
+        ALLOC(h->d_imu_acc, 3 * T * m);
+        ALLOC(h->d_imu_cov, 6 * T * m);
+        ALLOC(h->d_accel, 3 * T * m);
+        ALLOC(h->d_cov, 9 * T * m);
     }
     ALLOC(h->d_ranges, A * T * sizeof(int32_t));
-    ALLOC(h->d_err, A * T * r);
+    ALLOC(h->d_err, A * T * m);
     ALLOC(h->d_dt, T * sizeof(double));
     ALLOC(h->d_out, 15 * T * sizeof(double));
     ALLOC(h->d_status, T * sizeof(uint32_t));
@@ -530,7 +538,7 @@ int kfpos_set_init_positions(kfpos_handle *h, const double *xyz) {
     return stage_in(h, h->d_pos, xyz, 3, sizeof(double));
 }
 
-int kfpos_real_size(const kfpos_handle *h) { return h ? h->rsz : 0; }
+int kfpos_real_size(const kfpos_handle *h) { return h ? h->msz : 0; }
 int kfpos_state_dim(const kfpos_handle *h) { return h ? h->n : 0; }
 
 /* ---- device-buffer API ---- */
@@ -597,7 +605,7 @@ int kfpos_run_trace_dev(kfpos_handle *h, int32_t n_steps, const int32_t *range_m
     a.status = status;
     a.mode = accel ? MODE_FUSED : MODE_TOA;
     a.latch = 0;
-    const size_t r = h->rsz;
+    const size_t r = h->msz;
     for (int s = 0; s < n_steps; ++s) {
         a.ranges = range_mm + (size_t)s * stride_ranges;
         a.err = (const char *)err_est + (size_t)s * stride_err * r;
@@ -658,7 +666,7 @@ int kfpos_step_toa(kfpos_handle *h, const int32_t *range_mm, const void *err_est
     int rc = stage_dt(h, dt, dt_len, &d_dt, &shared);
     if (rc) return rc;
     if ((rc = stage_in(h, h->d_ranges, range_mm, h->cfg.max_anchors, sizeof(int32_t)))) return rc;
-    if ((rc = stage_in(h, h->d_err, err_est, h->cfg.max_anchors, h->rsz))) return rc;
+    if ((rc = stage_in(h, h->d_err, err_est, h->cfg.max_anchors, h->msz))) return rc;
     if ((rc = kfpos_step_toa_dev(h, h->d_ranges, h->d_err, d_dt, shared, h->d_status, nullptr))) return rc;
     return fetch_status(h, status);
 }
@@ -674,8 +682,8 @@ int kfpos_step_imu(kfpos_handle *h, const void *accel, const void *cov, const do
     double shared;
     int rc = stage_dt(h, dt, dt_len, &d_dt, &shared);
     if (rc) return rc;
-    if ((rc = stage_in(h, h->d_accel, accel, 3, h->rsz))) return rc;
-    if ((rc = stage_in(h, h->d_cov, cov, 9, h->rsz))) return rc;
+    if ((rc = stage_in(h, h->d_accel, accel, 3, h->msz))) return rc;
+    if ((rc = stage_in(h, h->d_cov, cov, 9, h->msz))) return rc;
     if ((rc = kfpos_step_imu_dev(h, h->d_accel, h->d_cov, d_dt, shared, h->d_status, nullptr))) return rc;
     return fetch_status(h, status);
 }
@@ -690,9 +698,9 @@ int kfpos_step_toa_imu(kfpos_handle *h, const int32_t *range_mm, const void *err
     int rc = stage_dt(h, dt, dt_len, &d_dt, &shared);
     if (rc) return rc;
     if ((rc = stage_in(h, h->d_ranges, range_mm, h->cfg.max_anchors, sizeof(int32_t)))) return rc;
-    if ((rc = stage_in(h, h->d_err, err_est, h->cfg.max_anchors, h->rsz))) return rc;
-    if ((rc = stage_in(h, h->d_accel, accel, 3, h->rsz))) return rc;
-    if ((rc = stage_in(h, h->d_cov, cov, 9, h->rsz))) return rc;
+    if ((rc = stage_in(h, h->d_err, err_est, h->cfg.max_anchors, h->msz))) return rc;
+    if ((rc = stage_in(h, h->d_accel, accel, 3, h->msz))) return rc;
+    if ((rc = stage_in(h, h->d_cov, cov, 9, h->msz))) return rc;
     if ((rc = kfpos_step_toa_imu_dev(h, h->d_ranges, h->d_err, h->d_accel, h->d_cov, 1, d_dt, shared,
                                      h->d_status, nullptr)))
         return rc;
@@ -722,18 +730,16 @@ int kfpos_get_state(kfpos_handle *h, double *x, double *P, uint32_t *flags) {
     if (x) {
         std::vector<double> pos(3 * T);
         HIPCHK(hipMemcpy(pos.data(), h->d_pos, pos.size() * sizeof(double), hipMemcpyDeviceToHost));
-        std::vector<unsigned char> vel;
+        std::vector<double> vel;
         if (n == 9) {
-            vel.resize(3 * T * h->rsz);
-            HIPCHK(hipMemcpy(vel.data(), h->d_vel, vel.size(), hipMemcpyDeviceToHost));
+            vel.resize(3 * T);
+            HIPCHK(hipMemcpy(vel.data(), h->d_vel, vel.size() * sizeof(double), hipMemcpyDeviceToHost));
         }
         for (size_t t = 0; t < T; ++t) {
             for (int k = 0; k < n; ++k) x[t * n + k] = 0.0;
             for (int k = 0; k < 3; ++k) {
                 x[t * n + k] = pos[(size_t)k * T + t];
-                if (n == 9)
-                    x[t * n + 3 + k] = h->rsz == 4 ? (double)((const float *)vel.data())[(size_t)k * T + t]
-                                                   : ((const double *)vel.data())[(size_t)k * T + t];
+                if (n == 9) x[t * n + 3 + k] = vel[(size_t)k * T + t];
             }
         }
     }
@@ -759,17 +765,14 @@ int kfpos_set_state(kfpos_handle *h, const double *x, const double *P, const uin
     const int n = h->n;
     if (x) {
         std::vector<double> pos(3 * T);
-        std::vector<unsigned char> vel(n == 9 ? 3 * T * h->rsz : 0);
+        std::vector<double> vel(n == 9 ? 3 * T : 0);
         for (size_t t = 0; t < T; ++t)
             for (int k = 0; k < 3; ++k) {
                 pos[(size_t)k * T + t] = x[t * n + k];
-                if (n == 9) {
-                    if (h->rsz == 4) ((float *)vel.data())[(size_t)k * T + t] = (float)x[t * n + 3 + k];
-                    else ((double *)vel.data())[(size_t)k * T + t] = x[t * n + 3 + k];
-                }
+                if (n == 9) vel[(size_t)k * T + t] = x[t * n + 3 + k];
             }
         HIPCHK(hipMemcpy(h->d_pos, pos.data(), pos.size() * sizeof(double), hipMemcpyHostToDevice));
-        if (n == 9) HIPCHK(hipMemcpy(h->d_vel, vel.data(), vel.size(), hipMemcpyHostToDevice));
+        if (n == 9) HIPCHK(hipMemcpy(h->d_vel, vel.data(), vel.size() * sizeof(double), hipMemcpyHostToDevice));
     }
     if (P) {
         std::vector<unsigned char> buf((size_t)h->psz * T * h->rsz);

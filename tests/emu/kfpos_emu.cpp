@@ -127,6 +127,30 @@ void kfe_step_imu(kfe_bank *b, const double *accel, const double *cov, const dou
     }
 }
 
+/* Emulate KFPOS_STORE_F32: what the step kernels keep in HBM between epochs is rounded to float
+ * (covariance when what&1, velocity when what&2); positions always stay double. */
+void kfe_round_storage(kfe_bank *b, int what) {
+    for (int t = 0; t < b->T; ++t) {
+        if (b->model == 1) {
+            if (what & 1) for (double &v : b->t9[t].P.a) v = (double)(float)v;
+            if (what & 2) for (double &v : b->t9[t].vel) v = (double)(float)v;
+            /* bits 4..9: round one 3x3 block pair only: pp, pv, pa, vv, va, aa */
+            const int bi[6] = {0, 0, 0, 3, 3, 6}, bj[6] = {0, 3, 6, 3, 6, 6};
+            for (int k = 0; k < 6; ++k)
+                if (what & (16 << k))
+                    for (int i = 0; i < 3; ++i)
+                        for (int j = 0; j < 3; ++j) {
+                            double &v = b->t9[t].P(bi[k] + i, bj[k] + j);
+                            v = (double)(float)v;
+                        }
+        } else if (b->full) {
+            if (what & 1) for (double &v : b->t6f[t].P.a) v = (double)(float)v;
+        } else {
+            if (what & 1) for (double &v : b->t6s[t].P.a) v = (double)(float)v;
+        }
+    }
+}
+
 /* x: T*n ([pos, vel(, 0)]), P: T*n*n full row-major */
 void kfe_get_state(const kfe_bank *b, double *x, double *P) {
     const int n = b->model == 1 ? 9 : 6;

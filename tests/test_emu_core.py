@@ -1,0 +1,64 @@
+"""CPU check of the kernel arithmetic (roskfpos_amd/csrc/kfpos_core.h compiled for the host).
+
+The HIP kernels evaluate the reference's iterated EKF in a restructured form (no m x m inverse, no
+pinv; see the header of kfpos_core.h). These tests run that exact text lane by lane on the CPU and
+compare it with the dense oracle, so the algebra is validated in the GPU-less container; the GPU
+tests then only have to show that the device build of the same text agrees.
+"""
+import numpy as np
+import pytest
+
+from cases import CASES, CASE_BY_NAME, drive, rms_and_max
+from impls import EmuImpl, OracleImpl
+
+# Bar from BASELINE.json: <= 1e-6 m RMS. Everything except the one documented case sits near 1e-12.
+TOL_RMS = {"toa6_A8_mlinit": 1e-6}
+TOL_DEFAULT_RMS, TOL_DEFAULT_MAX = 1e-9, 1e-8
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c.name for c in CASES])
+def test_kernel_math_matches_oracle(case):
+    fo, po, so = drive(case, OracleImpl, record=True)
+    fe, pe, se = drive(case, EmuImpl, record=True)
+    rms, mx, same_nan = rms_and_max(pe, po)
+    assert same_nan
+    if case.name in TOL_RMS:
+        # 6-state ML initialisation: the reference copies column 1 of the ML covariance twice
+        # (KalmanFilterTOA.cpp:102-104), which leaves a rank-5 NON-symmetric P for one epoch; there
+        # delta' pinv(P) delta has no closed form and the kernel's value of the convergence cost
+        # differs, so a few tags take one IEKF iteration more or fewer ("known deviation").
+        assert rms <= TOL_RMS[case.name], (rms, mx)
+        assert (so != se).mean() < 0.01
+    else:
+        assert rms <= TOL_DEFAULT_RMS and mx <= TOL_DEFAULT_MAX, (rms, mx)
+        assert np.array_equal(so, se)  # same iteration counts, same flags, same ignored anchor
+    xo, Po = fo.state()
+    xe, Pe = fe.state()
+    ok = np.isfinite(xo[:, 0])
+    scale = np.abs(Po[ok]).max()
+    assert np.abs(Po[ok] - Pe[ok]).max() <= (1e-4 if case.name in TOL_RMS else 1e-9) * scale
+    if case.model == 1:
+        assert np.abs(xo[ok, 3:6] - xe[ok, 3:6]).max() < 1e-8  # velocity is persisted by the 9-state filter
+
+
+@pytest.mark.parametrize("name", ["toa6_A8_fixed", "toa6_A8_mlinit", "imu9_A8_fixed"])
+def test_get_pose_extrapolation(name):
+    case = CASE_BY_NAME[name]
+    fo = drive(case, OracleImpl, steps=25)
+    fe = drive(case, EmuImpl, steps=25)
+    for dt_ahead in (0.0, 0.05, 0.37):
+        po, co, vo, _ = fo.pose(dt_ahead)
+        pe, ce, ve = fe.pose(dt_ahead)
+        assert np.allclose(pe, po, atol=1e-8 if name != "toa6_A8_mlinit" else 1e-4)
+        assert np.allclose(ce, co, rtol=1e-6, atol=1e-12 if name != "toa6_A8_mlinit" else 1e-7)
+        if case.model == 1:
+            assert np.allclose(ve, vo, atol=1e-8)
+
+
+def test_iteration_counts_are_in_the_surveyed_range():
+    # ~2.6 ML solves and ~2 gain iterations per step at 8 anchors (6-state)
+    case = CASE_BY_NAME["toa6_A8_fixed"]
+    _, _, st = drive(case, EmuImpl, record=True)
+    gain = (st >> 8) & 0xFF
+    ml = (st >> 16) & 0xFF
+    assert 1.5 < gain[10:].mean() < 3.5 and 1.5 < ml[10:].mean() < 4.5

@@ -1,0 +1,257 @@
+"""GPU parity tests: libkfpos_hip.so through the C ABI against the oracle, on the same seeded traces.
+
+Bar (BASELINE.json north_star): <= 1e-6 m RMS position difference vs the reference CPU EKF.
+All arithmetic is float64; KFPOS_STORE_F32 only narrows what is kept in HBM between steps.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from cases import CASES, CASE_BY_NAME, Case, drive, rms_and_max
+from impls import GpuImpl, OracleImpl
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+RMS_BAR = 1e-6  # metres, from BASELINE.json
+
+
+def _gpu(storage):
+    return lambda case, w, init: GpuImpl(case, w, init, storage=storage)
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c.name for c in CASES])
+def test_f64_storage_matches_oracle(case):
+    fo, po, so = drive(case, OracleImpl, record=True)
+    fg, pg, sg = drive(case, _gpu(0), record=True)
+    rms, mx, same_nan = rms_and_max(pg, po)
+    assert same_nan
+    if case.name == "toa6_A8_mlinit":
+        # non-symmetric rank-5 P for one epoch after the reference's ML-init column slip; see
+        # tests/test_emu_core.py and DESIGN.md "known deviation"
+        assert rms <= RMS_BAR, (rms, mx)
+        assert (so != sg).mean() < 0.01
+    else:
+        assert rms <= 1e-9 and mx <= 1e-8, (rms, mx)
+        assert np.array_equal(so, sg)  # iteration counts, flags and ignored anchors identical
+    xo, Po = fo.state()
+    xg, Pg = fg.state()
+    ok = np.isfinite(xo[:, 0])
+    assert np.abs(Po[ok] - Pg[ok]).max() <= (1e-4 if case.name == "toa6_A8_mlinit" else 1e-9) * np.abs(Po[ok]).max()
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c.name for c in CASES])
+def test_mixed_storage_matches_oracle(case):
+    """KFPOS_STORE_MIXED (f64 covariance, f32 measurements): the configuration bench.py measures."""
+    fo, po, so = drive(case, OracleImpl, real=np.float32, record=True)
+    fg, pg, sg = drive(case, _gpu(2), real=np.float32, record=True)
+    rms, mx, same_nan = rms_and_max(pg, po)
+    assert same_nan
+    if case.name == "toa6_A8_mlinit":
+        assert rms <= RMS_BAR, (rms, mx)
+    else:
+        assert rms <= 1e-9 and mx <= 1e-8, (rms, mx)
+        assert np.array_equal(so, sg)
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c.name for c in CASES])
+def test_f32_storage_on_edge_case_traces(case):
+    """KFPOS_STORE_F32: fp32 covariance + measurements, fp64 positions, velocities and arithmetic.
+
+    The 6-state filter stays ~1e-8 m from the oracle. The 9-state filter amplifies the 6e-8 relative
+    rounding of a 24-bit covariance to 1.6e-6 .. 2.5e-6 m RMS (also on the clean BASELINE trace), which is
+    above the 1e-6 m bar: F32 is therefore a documented reduced-accuracy mode for that filter (bound
+    checked here: 5e-6 m) and the parity configuration for BASELINE config 3 is KFPOS_STORE_MIXED."""
+    fo, po, so = drive(case, OracleImpl, real=np.float32, record=True)
+    fg, pg, sg = drive(case, _gpu(1), real=np.float32, record=True)
+    rms, mx, same_nan = rms_and_max(pg, po)
+    assert same_nan
+    assert rms <= (5e-6 if case.model == 1 else RMS_BAR), (rms, mx)
+
+
+@pytest.mark.parametrize("model,A,top_n,storage", [(1, 8, 0, 2), (0, 16, 2, 1), (0, 8, 0, 1)])
+def test_compact_storage_meets_the_rms_bar_on_baseline_traces(model, A, top_n, storage):
+    """BASELINE configs 3 / 5 / 2 shapes on the clean synthetic trace of SURVEY.md 8d, 512 tags x 100 steps:
+    config 3 with f32 measurements + f64 covariance, configs 5 and 2 with everything f32."""
+    from roskfpos_amd import capi
+    from roskfpos_amd.synth import Workload
+    import oracle_py
+    T, S = 512, 100
+    w = Workload(T, A)
+    e32, c32 = w.err_est(np.float32), w.accel_cov(np.float32)
+    gpu = capi.KfposBank(model, T, w.anchors, storage=storage, top_n=top_n, init_pos=w.init_positions())
+    orc = oracle_py.OracleBank(model, T, w.anchors, top_n=top_n, init_pos=w.init_positions(), n_threads=8)
+    sq = 0.0
+    for s in range(S):
+        r, a32, dt = w.ranges_mm(s), w.accel(s, np.float32), w.dt_of(s)
+        if model == 1:
+            gpu.step_toa_imu(r, e32, a32, c32, dt)
+            orc.step_imu(a32.astype(np.float64), c32.astype(np.float64), 0.0)
+        else:
+            gpu.step_toa(r, e32, dt)
+        orc.step_toa(r, e32.astype(np.float64), dt)
+        xg, _, _ = gpu.get_state()
+        xo, _ = orc.get_state()
+        sq += ((xg[:, :3] - xo[:, :3]) ** 2).sum()
+    rms = np.sqrt(sq / (T * S))
+    assert rms <= RMS_BAR, rms
+
+
+@pytest.mark.parametrize("name", sorted(CASE_BY_NAME))
+def test_gpu_reproduces_golden_fixture(name):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    c = CASE_BY_NAME[name]
+    f, pos, st = drive(c, _gpu(0), steps=int(g["steps"]), record=True)
+    rms, mx, same_nan = rms_and_max(pos, g["positions"])
+    assert same_nan and rms <= (RMS_BAR if name == "toa6_A8_mlinit" else 1e-9), (rms, mx)
+    if name != "toa6_A8_mlinit":
+        assert np.array_equal(st, g["status"])
+
+
+@pytest.mark.parametrize("name", ["toa6_A8_fixed", "imu9_A8_fixed"])
+def test_get_pose_and_idempotence(name):
+    case = CASE_BY_NAME[name]
+    fo = drive(case, OracleImpl, steps=20)
+    fg = drive(case, _gpu(0), steps=20)
+    x0, P0 = fg.state()
+    for dt_ahead in (0.0, 0.05, 0.4):
+        po, co, vo, _ = fo.pose(dt_ahead)
+        pg, cg, vg, stg = fg.pose(dt_ahead)
+        assert np.all(stg == 0)
+        assert np.allclose(pg, po, atol=1e-9) and np.allclose(cg, co, rtol=1e-7, atol=1e-13)
+        if case.model == 1:
+            assert np.allclose(vg, vo, atol=1e-9)
+    x1, P1 = fg.state()
+    assert np.array_equal(x0, x1) and np.array_equal(P0, P1)  # getPose never modifies the filter
+
+
+def test_not_started_and_empty_epochs():
+    from roskfpos_amd import capi
+    from roskfpos_amd.synth import Workload
+    w = Workload(70, 8)  # not a multiple of the wavefront width: ragged last workgroup
+    b = capi.KfposBank(capi.MODEL_TOA, 70, w.anchors, init_pos=w.init_positions())
+    pos, cov, vel, st = b.get_pose(0.1)
+    assert np.all(st == capi.ST_NOT_STARTED) and np.all(np.isnan(pos))
+    st = b.step_toa(np.zeros((70, 8), dtype=np.int32), w.err_est(), 0.1)  # no range at all
+    assert np.all(st & capi.ST_FEW_RANGES)
+    x, P, fl = b.get_state()
+    assert np.allclose(x[:, :3], w.init_positions()) and np.all(fl & 1)
+    # state round trip (checkpoint / restore)
+    b2 = capi.KfposBank(capi.MODEL_TOA, 70, w.anchors, init_pos=w.init_positions())
+    b2.set_state(x, P, fl)
+    r = w.ranges_mm(1)
+    b.step_toa(r, w.err_est(), 0.05)
+    b2.step_toa(r, w.err_est(), 0.05)
+    xa, Pa, _ = b.get_state()
+    xb, Pb, _ = b2.get_state()
+    assert np.array_equal(xa, xb) and np.array_equal(Pa, Pb)
+
+
+def test_argument_errors():
+    from roskfpos_amd import capi
+    from roskfpos_amd.synth import anchors_xyz
+    with pytest.raises(capi.KfposError):
+        capi.KfposBank(7, 4, anchors_xyz(4), init_pos=np.zeros(3))          # unknown model
+    with pytest.raises(capi.KfposError):
+        capi.KfposBank(capi.MODEL_TOA, 0, anchors_xyz(4), init_pos=np.zeros(3))  # no tags
+    with pytest.raises(capi.KfposError):
+        capi.KfposBank(capi.MODEL_TOA_IMU, 4, anchors_xyz(4), top_n=1, init_pos=np.zeros(3))
+    b = capi.KfposBank(capi.MODEL_TOA, 4, anchors_xyz(4), init_pos=np.zeros(3))
+    with pytest.raises(capi.KfposError):
+        b.step_toa_imu(np.ones((4, 4), dtype=np.int32), np.ones((4, 4)), np.zeros((4, 3)), np.zeros((4, 9)), 0.1)
+
+
+def _torch_trace(w, S, real):
+    import torch
+    r, a, dt = w.trace(S)
+    dev = "cuda:0"
+    rt = torch.from_numpy(np.ascontiguousarray(r.transpose(0, 2, 1))).to(dev)               # [S][A][T]
+    at = torch.from_numpy(np.ascontiguousarray(a.transpose(0, 2, 1)).astype(real)).to(dev)  # [S][3][T]
+    et = torch.from_numpy(np.ascontiguousarray(w.err_est(real).T)).to(dev)                  # [A][T]
+    ct = torch.from_numpy(np.ascontiguousarray(w.accel_cov(real).T)).to(dev)                # [9][T]
+    return r, a, dt, rt, at, et, ct
+
+
+@pytest.mark.parametrize("model,storage", [(0, 0), (1, 0), (1, 1), (1, 2)])
+def test_device_api_and_trace_replay_equal_host_api(model, storage):
+    """Device-pointer entry points (component-major, torch-owned HBM) == host-buffer entry points."""
+    import torch
+    from roskfpos_amd import capi
+    from roskfpos_amd.synth import Workload
+    T, A, S = 1000, 8, 12
+    real = np.float32 if storage else np.float64
+    w = Workload(T, A)
+    r, a, dt, rt, at, et, ct = _torch_trace(w, S, real)
+    host = capi.KfposBank(model, T, w.anchors, storage=storage, init_pos=w.init_positions())
+    dev = capi.KfposBank(model, T, w.anchors, storage=storage, init_pos=w.init_positions())
+    rep = capi.KfposBank(model, T, w.anchors, storage=storage, init_pos=w.init_positions())
+    st_t = torch.zeros(T, dtype=torch.int32, device="cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    for s in range(S):
+        if model == 1:
+            sh = host.step_toa_imu(r[s], w.err_est(real), a[s].astype(real), w.accel_cov(real), dt[s])
+            dev.step_toa_imu_dev(rt[s], et, at[s], ct, dt[s], status=st_t, stream=stream)
+        else:
+            sh = host.step_toa(r[s], w.err_est(real), dt[s])
+            dev.step_toa_dev(rt[s], et, dt[s], status=st_t, stream=stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(sh, st_t.cpu().numpy().astype(np.uint32))
+    if model == 1:
+        rep.run_trace_dev(S, rt, A * T, et, 0, dt, accel=at, stride_accel=3 * T, cov=ct, stride_cov=0,
+                          stream=stream)
+    else:
+        rep.run_trace_dev(S, rt, A * T, et, 0, dt, stream=stream)
+    torch.cuda.synchronize()
+    xh, Ph, _ = host.get_state()
+    for other in (dev, rep):
+        xo, Po, _ = other.get_state()
+        assert np.array_equal(xh, xo) and np.array_equal(Ph, Po)
+    # pose straight into torch memory, component-major
+    pos_t = torch.zeros(3, T, dtype=torch.float64, device="cuda:0")
+    dev.get_pose_dev(0.05, pos=pos_t, stream=stream)
+    torch.cuda.synchronize()
+    ph, _, _, _ = host.get_pose(0.05)
+    assert np.array_equal(pos_t.cpu().numpy().T, ph)
+
+
+def test_full_size_properties_config3():
+    """BASELINE config 3 at full size (65 536 tags x 8 anchors, 9-state, f32 measurements, f64 covariance):
+    size-independent properties plus an oracle check on a strided sample of the tags."""
+    import torch
+    from roskfpos_amd import capi
+    from roskfpos_amd.synth import Workload
+    import oracle_py
+    T, A, S = 65536, 8, 10
+    w = Workload(T, A)
+    r, a, dt, rt, at, et, ct = _torch_trace(w, S, np.float32)
+    stream = torch.cuda.current_stream().cuda_stream
+    full = capi.KfposBank(capi.MODEL_TOA_IMU, T, w.anchors, storage=2, init_pos=w.init_positions())
+    full.run_trace_dev(S, rt, A * T, et, 0, dt, accel=at, stride_accel=3 * T, cov=ct, stride_cov=0, stream=stream)
+    torch.cuda.synchronize()
+    xf, Pf, _ = full.get_state()
+    assert np.all(np.isfinite(xf)) and np.all(np.isfinite(Pf))
+    # (1) shard equivalence: tags are independent, so any shard run alone is bit-identical
+    lo, hi = 3 * 8192, 4 * 8192
+    ws = Workload(hi - lo, A, tag0=lo)
+    shard = capi.KfposBank(capi.MODEL_TOA_IMU, hi - lo, w.anchors, storage=2, init_pos=ws.init_positions())
+    for s in range(S):
+        shard.step_toa_imu(ws.ranges_mm(s), ws.err_est(np.float32), ws.accel(s, np.float32),
+                           ws.accel_cov(np.float32), dt[s])
+    xs, Ps, _ = shard.get_state()
+    assert np.array_equal(xs, xf[lo:hi]) and np.array_equal(Ps, Pf[lo:hi])
+    # (2) covariance stays symmetric positive semi-definite on its position block, and tracks the truth
+    truth = w.position(w.time_of(S - 1))
+    assert np.sqrt(((xf[:, :3] - truth) ** 2).sum(1).mean()) < 0.5
+    assert np.all(np.linalg.eigvalsh(Pf[::997, :3, :3]) > -1e-9)
+    # (3) oracle on every 257th tag
+    idx = np.arange(0, T, 257)
+    orc = oracle_py.OracleBank(1, len(idx), w.anchors, init_pos=w.init_positions()[idx], n_threads=8)
+    e64 = w.err_est(np.float32).astype(np.float64)[idx]
+    c64 = w.accel_cov(np.float32).astype(np.float64)[idx]
+    for s in range(S):
+        orc.step_imu(a[s].astype(np.float32).astype(np.float64)[idx], c64, 0.0)
+        orc.step_toa(r[s][idx], e64, dt[s])
+    xo, _ = orc.get_state()
+    rms = np.sqrt(((xo[:, :3] - xf[idx, :3]) ** 2).sum(1).mean())
+    assert rms <= RMS_BAR, rms
