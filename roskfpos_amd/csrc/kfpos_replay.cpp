@@ -1,0 +1,188 @@
+/*
+ * kfpos_replay.cpp -- ROS-free trace replay through the host adaptor (kfpos_adaptor.h).
+ *
+ * Stands where PosGenerator + node_pos.cpp stand in the reference: it takes the launch-file
+ * parameters by their reference names (node_pos.cpp:48-109, roslaunch `name:=value` syntax), builds
+ * the estimator the way PosGenerator::setAlgorithm does (Posgenerator.cpp:510-538), assembles ranging
+ * messages into epochs by sequence number (Posgenerator.cpp:201-281, 476-496) and prints poses.
+ * ROS itself is not available in this image, so messages come from a text trace:
+ *
+ *   A <anchorId> <x> <y> <z>                          anchors topic (Posgenerator.cpp:15-39)
+ *   R <t> <anchorId> <tagId> <range_mm> <seq> <err>   gtec_msgs::Ranging (one per tag-anchor range)
+ *   I <t> <ax> <ay> <az> <c0> ... <c8>                sensor_msgs::Imu linear acceleration + covariance
+ *   P <t>                                             fixed-rate publish tick -> getPose (Posgenerator.cpp:541-548)
+ *   F <t>                                             flush the open epoch (the 50 ms timer, Posgenerator.cpp:143-152)
+ *
+ * Output: one line per P tick: "P <t> <ok> <x> <y> <z> <cov00> <cov11> <cov22>".
+ */
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <memory>
+#include <sstream>
+#include <string>
+
+#include "kfpos_adaptor.h"
+
+using namespace kfpos_host;
+
+struct NodeParams { /* names and defaults: node_pos.cpp:48-109, kfpos_toa.launch, kfpos_toa_imu.launch */
+    std::string algorithm = "ALGORITHM_KF_TOA";
+    std::string toaTagId = ""; /* the node reads toaTagId, not the launch files' tagId (node_pos.cpp:63) */
+    double accelNoise = 0.5, jolt = 0.5;
+    int useStartPosition = 0;
+    double initPositionX = 0, initPositionY = 0, initPositionZ = 0;
+    int useHeuristicIgnoreWorst = 0;
+    double heuristicIgnoreThreshold = 0.5;
+};
+
+static bool set_param(NodeParams &p, const std::string &k, const std::string &v) {
+    if (k == "algorithm") p.algorithm = v;
+    else if (k == "toaTagId") p.toaTagId = v;
+    else if (k == "accelNoise") p.accelNoise = atof(v.c_str());
+    else if (k == "jolt") p.jolt = atof(v.c_str());
+    else if (k == "useStartPosition") p.useStartPosition = atoi(v.c_str());
+    else if (k == "initPositionX") p.initPositionX = atof(v.c_str());
+    else if (k == "initPositionY") p.initPositionY = atof(v.c_str());
+    else if (k == "initPositionZ") p.initPositionZ = atof(v.c_str());
+    else if (k == "useHeuristicIgnoreWorst") p.useHeuristicIgnoreWorst = atoi(v.c_str());
+    else if (k == "heuristicIgnoreThreshold") p.heuristicIgnoreThreshold = atof(v.c_str());
+    else return false;
+    return true;
+}
+
+/* PosGenerator::setAlgorithm, Posgenerator.cpp:510-538 */
+static std::unique_ptr<SingleTagFilter> make_algorithm(const NodeParams &p) {
+    Vector3 init;
+    init.x = p.initPositionX; init.y = p.initPositionY; init.z = p.initPositionZ;
+    if (p.algorithm == "ALGORITHM_KF_TOA") {
+        /* sic: the reference's branch is inverted here (Posgenerator.cpp:512-516): WITHOUT
+         * useStartPosition the fixed-initial-position constructor is chosen */
+        if (!p.useStartPosition)
+            return std::unique_ptr<SingleTagFilter>(new KalmanFilterTOA(
+                p.accelNoise, p.useHeuristicIgnoreWorst != 0, p.heuristicIgnoreThreshold, init));
+        return std::unique_ptr<SingleTagFilter>(
+            new KalmanFilterTOA(p.accelNoise, p.useHeuristicIgnoreWorst != 0, p.heuristicIgnoreThreshold));
+    }
+    if (p.algorithm == "ALGORITHM_KF_TOA_IMU") {
+        if (!p.useStartPosition) return std::unique_ptr<SingleTagFilter>(new KalmanFilterTOAIMU(p.accelNoise, p.jolt));
+        return std::unique_ptr<SingleTagFilter>(new KalmanFilterTOAIMU(p.accelNoise, p.jolt, init));
+    }
+    throw std::invalid_argument("algorithm must be ALGORITHM_KF_TOA or ALGORITHM_KF_TOA_IMU "
+                                "(ALGORITHM_KF / ALGORITHM_ML are outside this core: DESIGN.md)");
+}
+
+/* The ranging epoch table of PosGenerator for one tag: ranges keyed by anchor column, flushed when a
+ * message with a new sequence number arrives (Posgenerator.cpp:229-272). */
+struct EpochAssembler {
+    std::map<int, int> column; /* anchor id -> column (_anchorIndexById) */
+    std::vector<Beacon> beacons;
+    int seq = -1;
+    std::vector<int> mm;
+    std::vector<double> err;
+
+    void addAnchor(int id, double x, double y, double z) {
+        if (column.count(id)) return;
+        Beacon b;
+        b.id = id;
+        b.index = (int)beacons.size();
+        b.position.x = x; b.position.y = y; b.position.z = z;
+        column[id] = b.index;
+        beacons.push_back(b);
+        mm.assign(beacons.size(), -1);
+        err.assign(beacons.size(), 0.0);
+    }
+    /* calculateTagLocationWithRangings, Posgenerator.cpp:476-496 */
+    void flush(PositionEstimationAlgorithm &alg) {
+        if (seq < 0) return;
+        std::vector<double> r, e;
+        std::vector<Beacon> sel;
+        for (size_t i = 0; i < mm.size(); ++i)
+            if (mm[i] > 0) {
+                r.push_back((double)mm[i] / 1000);
+                e.push_back(err[i]);
+                sel.push_back(beacons[i]);
+            }
+        alg.newTOAMeasurement(r, sel, e, 0.0);
+        std::fill(mm.begin(), mm.end(), -1);
+        seq = -1;
+    }
+    void ranging(PositionEstimationAlgorithm &alg, int anchorId, double range_mm, int s, double e) {
+        if (!column.count(anchorId)) return; /* dropped until the anchor is known (Posgenerator.cpp:92-96) */
+        if (seq >= 0 && s != seq) flush(alg);
+        seq = s;
+        mm[column[anchorId]] = (int)std::floor(range_mm); /* Posgenerator.cpp:213 */
+        err[column[anchorId]] = e;
+    }
+};
+
+int main(int argc, char **argv) {
+    NodeParams p;
+    std::string trace;
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        const size_t k = a.find(":=");
+        if (k == std::string::npos) { trace = a; continue; }
+        if (!set_param(p, a.substr(0, k), a.substr(k + 2))) {
+            fprintf(stderr, "unknown parameter %s\n", a.substr(0, k).c_str());
+            return 2;
+        }
+    }
+    if (trace.empty()) {
+        fprintf(stderr, "usage: kfpos_replay [name:=value ...] trace.txt\n");
+        return 2;
+    }
+    int tagId = 0; /* hex parse, default 0 (node_pos.cpp:139-144) */
+    if (!p.toaTagId.empty()) tagId = (int)strtol(p.toaTagId.c_str(), nullptr, 16);
+
+    try {
+        std::unique_ptr<SingleTagFilter> alg = make_algorithm(p);
+        double now = 0.0;
+        alg->setClock([&now] { return now; });
+        alg->init();
+        EpochAssembler ep;
+        std::ifstream in(trace);
+        std::string line;
+        while (std::getline(in, line)) {
+            if (line.empty() || line[0] == '#') continue;
+            std::istringstream ss(line);
+            char kind;
+            ss >> kind;
+            if (kind == 'A') {
+                int id; double x, y, z;
+                ss >> id >> x >> y >> z;
+                ep.addAnchor(id, x, y, z);
+            } else if (kind == 'R') {
+                int anchorId, tag, seq; double t, mm, e;
+                ss >> t >> anchorId >> tag >> mm >> seq >> e;
+                if (tag != tagId) continue; /* Posgenerator.cpp:203 */
+                now = t;
+                ep.ranging(*alg, anchorId, mm, seq, e);
+            } else if (kind == 'F') {
+                ss >> now;
+                ep.flush(*alg);
+            } else if (kind == 'I') {
+                double t, c[9]; VectorDim3 a, w = {0, 0, 0};
+                ss >> t >> a.x >> a.y >> a.z;
+                for (double &v : c) ss >> v;
+                now = t;
+                double cw[9] = {0};
+                alg->newIMUMeasurement(w, cw, a, c);
+            } else if (kind == 'P') {
+                ss >> now;
+                Vector3 pose;
+                pose.x = pose.y = pose.z = NAN;
+                const bool ok = alg->getPose(pose);
+                const int d = pose.covarianceDim ? pose.covarianceDim : 6;
+                printf("P %.9f %d %.17g %.17g %.17g %.17g %.17g %.17g\n", now, ok ? 1 : 0, pose.x, pose.y, pose.z,
+                       pose.covarianceMatrix[0], pose.covarianceMatrix[d + 1], pose.covarianceMatrix[2 * d + 2]);
+            }
+        }
+    } catch (const std::exception &e) {
+        fprintf(stderr, "kfpos_replay: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

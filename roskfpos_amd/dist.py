@@ -39,7 +39,9 @@ class PoseGather:
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         dtype = dtype or torch.float64
         self.local = [torch.zeros(3, t_local, dtype=dtype, device=device) for _ in range(2)]
-        self.full = [torch.zeros(self.world, 3, t_local, dtype=dtype, device=device) for _ in range(2)]
+        # concatenation form [world*3][T_local] (what every backend accepts); handed out as [world][3][T_local]
+        self.flat = [torch.zeros(self.world * 3, t_local, dtype=dtype, device=device) for _ in range(2)]
+        self.full = [f.view(self.world, 3, t_local) for f in self.flat]
         self.cuda = torch.device(device).type == "cuda"
         self.overlap = overlap and self.cuda
         if self.cuda:
@@ -68,11 +70,11 @@ class PoseGather:
             self.ready[b].record(self.torch.cuda.current_stream())
             with self.torch.cuda.stream(self.comm):
                 self.comm.wait_event(self.ready[b])
-                self.dist.all_gather_into_tensor(self.full[b], self.local[b])
+                self.dist.all_gather_into_tensor(self.flat[b], self.local[b])
                 self.done[b].record(self.comm)
             self.used[b] = True
         else:
-            self.dist.all_gather_into_tensor(self.full[b], self.local[b])
+            self.dist.all_gather_into_tensor(self.flat[b], self.local[b])
         return self.full[b]
 
     def wait(self):
