@@ -1,10 +1,11 @@
 /*
  * kfpos_core.h -- per-tag arithmetic of the batched EKF core (one filter per lane).
  *
- * This is the body every HIP kernel in kfpos_kernels.hip runs for one tag. It is written
- * against plain doubles and compile-time-indexed arrays only (everything unrolls into
- * registers; no HIP intrinsic appears here), so the same text also compiles with g++ into
- * the host emulation used by the CPU tests (tests/emu) to check the algebra without a GPU.
+ * This is the body every HIP kernel in kfpos_hip.hip runs for one tag. It is written against
+ * plain doubles and compile-time-indexed arrays only (everything unrolls into registers; the
+ * only device builtins are the v_rcp_f64 / v_rsq_f64 seeds in kf_rcp / kf_rsqrt), so the same
+ * text also compiles with g++ into the host emulation used by the CPU tests (tests/emu) to
+ * check the algebra without a GPU.
  *
  * What it computes is the reference's iterated EKF, restructured
  * for a register-resident, branch-light evaluation -- results equal the reference's to
@@ -37,6 +38,7 @@
 #ifndef KFPOS_HD
 #define KFPOS_HD
 #endif
+#define KFPOS_FN KFPOS_HD inline __attribute__((always_inline))
 #if defined(__clang__)
 #define KFPOS_UNROLL _Pragma("unroll")
 #else
@@ -57,14 +59,53 @@ enum : uint32_t {
 /* persisted per-tag flag bits */
 enum : uint32_t { FL_STARTED = 1u, FL_HAS_IMU = 2u };
 
-KFPOS_HD inline uint32_t pack_status(uint32_t flags, int gain_iters, int ml_iters, int ignored) {
+KFPOS_FN uint32_t pack_status(uint32_t flags, int gain_iters, int ml_iters, int ignored) {
     const uint32_t g = gain_iters > 255 ? 255u : (uint32_t)gain_iters;
     const uint32_t m = ml_iters > 255 ? 255u : (uint32_t)ml_iters;
     return flags | (g << 8) | (m << 16) | ((uint32_t)(ignored + 1) << 24);
 }
 
+/* Reciprocal, reciprocal square root and square root to ~1 ulp: hardware seed + two Newton steps
+ * (8-10 fp64 instructions instead of the ~20-30 of an IEEE-exact divide / sqrt sequence; the parity
+ * bar is 1e-6 m, not the last bit -- the reference's own LAPACK arithmetic is not reproducible to
+ * the last bit either). The host emulation uses the plain operators. */
+KFPOS_FN double kf_rcp(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double y = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-x, y, 1.0);
+    return __builtin_fma(y, e, y);
+#else
+    return 1.0 / x;
+#endif
+}
+KFPOS_FN double kf_rsqrt(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double y = __builtin_amdgcn_rsq(x);
+    const double h = 0.5 * x;
+    double e = __builtin_fma(-h * y, y, 0.5);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-h * y, y, 0.5);
+    return __builtin_fma(y, e, y);
+#else
+    return 1.0 / sqrt(x);
+#endif
+}
+/* d = sqrt(x) and invd = 1/sqrt(x) together (x > 0) */
+KFPOS_FN void kf_sqrt_rsqrt(double x, double &d, double &invd) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    invd = kf_rsqrt(x);
+    const double s = x * invd;
+    d = __builtin_fma(__builtin_fma(-s, s, x) * 0.5, invd, s);
+#else
+    d = sqrt(x);
+    invd = 1.0 / d;
+#endif
+}
+
 /* std::max as the reference uses it: (a < b) ? b : a (matters for NaN) */
-KFPOS_HD inline double stdmax(double a, double b) { return (a < b) ? b : a; }
+KFPOS_FN double stdmax(double a, double b) { return (a < b) ? b : a; }
 
 /* ------------------------------------------------------------------ covariance storage */
 /* Packed upper triangle (symmetric) or full row-major. All indices are compile-time after
@@ -91,7 +132,7 @@ struct Params {
 
 /* ------------------------------------------------------------------ 3x3 helpers */
 /* inverse of a symmetric 3x3 {00,01,02,11,12,22} by cofactors; returns det */
-KFPOS_HD inline double sym3_cofactors(const double h[6], double c[6]) {
+KFPOS_FN double sym3_cofactors(const double h[6], double c[6]) {
     c[0] = h[3] * h[5] - h[4] * h[4];
     c[1] = h[2] * h[4] - h[1] * h[5];
     c[2] = h[1] * h[4] - h[2] * h[3];
@@ -101,7 +142,7 @@ KFPOS_HD inline double sym3_cofactors(const double h[6], double c[6]) {
     return h[0] * c[0] + h[1] * c[1] + h[2] * c[2];
 }
 /* adjugate of a general 3x3 (row-major), returns det; inverse = adj / det */
-KFPOS_HD inline double gen3_adjugate(const double m[9], double adj[9]) {
+KFPOS_FN double gen3_adjugate(const double m[9], double adj[9]) {
     adj[0] = m[4] * m[8] - m[5] * m[7];
     adj[1] = m[2] * m[7] - m[1] * m[8];
     adj[2] = m[1] * m[5] - m[2] * m[4];
@@ -118,23 +159,26 @@ KFPOS_HD inline double gen3_adjugate(const double m[9], double adj[9]) {
  * rounding level marks a rank-deficient direction (fewer than 3 independent ranges): its
  * column is zeroed, which is the semidefinite factor (M = L L' still holds).
  * l = {l00,l10,l20,l11,l21,l22}, il = reciprocals of the diagonal (0 for a dropped column). */
-KFPOS_HD inline void chol3_psd(const double m[6], double l[6], double il[3]) {
+KFPOS_FN void chol3_psd(const double m[6], double l[6], double il[3]) {
     const double REL = 1e-12;
-    double d = m[0];
+    double d = m[0], sq, isq;
     bool ok = d > 0.0;
-    l[0] = ok ? sqrt(d) : 0.0;
-    il[0] = ok ? 1.0 / l[0] : 0.0;
+    kf_sqrt_rsqrt(ok ? d : 1.0, sq, isq);
+    l[0] = ok ? sq : 0.0;
+    il[0] = ok ? isq : 0.0;
     l[1] = m[1] * il[0];
     l[2] = m[2] * il[0];
     d = m[3] - l[1] * l[1];
     ok = d > REL * m[3];
-    l[3] = ok ? sqrt(d) : 0.0;
-    il[1] = ok ? 1.0 / l[3] : 0.0;
+    kf_sqrt_rsqrt(ok ? d : 1.0, sq, isq);
+    l[3] = ok ? sq : 0.0;
+    il[1] = ok ? isq : 0.0;
     l[4] = (m[4] - l[2] * l[1]) * il[1];
     d = m[5] - l[2] * l[2] - l[4] * l[4];
     ok = d > REL * m[5];
-    l[5] = ok ? sqrt(d) : 0.0;
-    il[2] = ok ? 1.0 / l[5] : 0.0;
+    kf_sqrt_rsqrt(ok ? d : 1.0, sq, isq);
+    l[5] = ok ? sq : 0.0;
+    il[2] = ok ? isq : 0.0;
 }
 
 /* ------------------------------------------------------------------ measurement scratch */
@@ -142,19 +186,50 @@ KFPOS_HD inline void chol3_psd(const double m[6], double l[6], double il[3]) {
  * w = working weight (1/e during ML, 1/R during the IEKF). Element a lives at base[a*stride]:
  * stride = wavefront width in LDS (conflict-free), 1 in the host emulation. */
 struct Scratch {
+    static constexpr int NA = 0; /* anchor count only known at run time */
     double *r, *e, *w;
     int stride;
     KFPOS_HD double R(int a) const { return r[a * stride]; }
     KFPOS_HD double E(int a) const { return e[a * stride]; }
     KFPOS_HD double W(int a) const { return w[a * stride]; }
-    KFPOS_HD void setW(int a, double v) const { w[a * stride] = v; }
+    KFPOS_HD void setW(int a, double v) { w[a * stride] = v; }
+    KFPOS_HD double Rdyn(int a) const { return r[a * stride]; } /* a not a compile-time constant */
 };
-KFPOS_HD inline bool used(const Scratch &sc, int a, uint64_t drop) {
+/* Same view with the anchor count fixed at compile time: the epoch stays in registers, every anchor
+ * loop unrolls, anchor coordinates become constant-offset scalar loads that the compiler batches. */
+template <int N>
+struct RegScratch {
+    static constexpr int NA = N;
+    double r[N], e[N], w[N];
+    KFPOS_HD double R(int a) const { return r[a]; }
+    KFPOS_HD double E(int a) const { return e[a]; }
+    KFPOS_HD double W(int a) const { return w[a]; }
+    KFPOS_HD void setW(int a, double v) { w[a] = v; }
+    KFPOS_HD double Rdyn(int a) const { /* run-time index without sending the array to scratch memory */
+        double v = 0.0;
+        KFPOS_UNROLL
+        for (int k = 0; k < N; ++k) v = (k == a) ? r[k] : v;
+        return v;
+    }
+};
+/* f(a) for every anchor column; fully unrolled when the count is static */
+template <class SC, class F>
+KFPOS_FN void for_anchors(const Params &pr, F &&f) {
+    if constexpr (SC::NA > 0) {
+        KFPOS_UNROLL
+        for (int a = 0; a < SC::NA; ++a) f(a);
+    } else {
+        for (int a = 0; a < pr.n_anchors; ++a) f(a);
+    }
+}
+template <class SC>
+KFPOS_FN bool used(const SC &sc, int a, uint64_t drop) {
     return !((drop >> a) & 1ull) && sc.R(a) > 0.0;
 }
-KFPOS_HD inline int count_used(const Scratch &sc, int A, uint64_t drop) {
+template <class SC>
+KFPOS_FN int count_used(const SC &sc, const Params &pr, uint64_t drop) {
     int n = 0;
-    for (int a = 0; a < A; ++a) n += used(sc, a, drop) ? 1 : 0;
+    for_anchors<SC>(pr, [&](int a) { n += used(sc, a, drop) ? 1 : 0; });
     return n;
 }
 
@@ -162,55 +237,62 @@ KFPOS_HD inline int count_used(const Scratch &sc, int A, uint64_t drop) {
 /* One sweep over the anchors at position p: weighted cost sum (r-d)^2/e, unweighted SSE
  * (estimationError, MLLocation.cpp:263-278), gradient g and Hessian-like Hs of
  * MLLocation.cpp:174-204 (Hs symmetric, packed {00,01,02,11,12,22}). */
-KFPOS_HD inline void ml_sweep(const double p[3], const Scratch &sc, const Params &pr, uint64_t drop,
+template <class SC>
+KFPOS_FN void ml_sweep(const double p[3], const SC &sc, const Params &pr, uint64_t drop,
                               double &cw, double &sse, double g[3], double hs[6]) {
-    cw = 0.0;
-    sse = 0.0;
-    g[0] = g[1] = g[2] = 0.0;
-    KFPOS_UNROLL
-    for (int k = 0; k < 6; ++k) hs[k] = 0.0;
-    for (int a = 0; a < pr.n_anchors; ++a) {
-        if (!used(sc, a, drop)) continue;
+    double cw_ = 0.0, sse_ = 0.0, g0 = 0.0, g1 = 0.0, g2 = 0.0;
+    double h0 = 0.0, h1 = 0.0, h2 = 0.0, h3 = 0.0, h4 = 0.0, h5 = 0.0;
+    for_anchors<SC>(pr, [&](int a) {
+        if (!used(sc, a, drop)) return;
         const double r = sc.R(a), w = sc.W(a);
         const double dx = pr.anchors[3 * a] - p[0], dy = pr.anchors[3 * a + 1] - p[1],
                      dz = pr.anchors[3 * a + 2] - p[2];
-        const double d = sqrt(dx * dx + dy * dy + dz * dz);
-        const double rd = r - d, invd = 1.0 / d;
-        cw += rd * rd * w;
-        sse += rd * rd;
+        double d, invd;
+        kf_sqrt_rsqrt(dx * dx + dy * dy + dz * dz, d, invd);
+        const double rd = r - d;
+        cw_ += rd * rd * w;
+        sse_ += rd * rd;
         const double gi = rd * invd * w;
-        g[0] += gi * dx;
-        g[1] += gi * dy;
-        g[2] += gi * dz;
+        g0 += gi * dx;
+        g1 += gi * dy;
+        g2 += gi * dz;
         const double q = r * invd;
         const double c0 = w * (1.0 - q), c1 = w * q * invd * invd;
-        hs[0] += c0 + c1 * dx * dx;
-        hs[1] += c1 * dx * dy;
-        hs[2] += c1 * dx * dz;
-        hs[3] += c0 + c1 * dy * dy;
-        hs[4] += c1 * dy * dz;
-        hs[5] += c0 + c1 * dz * dz;
-    }
+        h0 += c0 + c1 * dx * dx;
+        h1 += c1 * dx * dy;
+        h2 += c1 * dx * dz;
+        h3 += c0 + c1 * dy * dy;
+        h4 += c1 * dy * dz;
+        h5 += c0 + c1 * dz * dz;
+    });
+    cw = cw_; sse = sse_;
+    g[0] = g0; g[1] = g1; g[2] = g2;
+    hs[0] = h0; hs[1] = h1; hs[2] = h2; hs[3] = h3; hs[4] = h4; hs[5] = h5;
 }
 
 /* SSE only (estimationError at a given position) */
-KFPOS_HD inline double ml_sse(const double p[3], const Scratch &sc, const Params &pr, uint64_t drop) {
+template <class SC>
+KFPOS_FN double ml_sse(const double p[3], const SC &sc, const Params &pr, uint64_t drop) {
     double sse = 0.0;
-    for (int a = 0; a < pr.n_anchors; ++a) {
-        if (!used(sc, a, drop)) continue;
+    for_anchors<SC>(pr, [&](int a) {
+        if (!used(sc, a, drop)) return;
         const double dx = pr.anchors[3 * a] - p[0], dy = pr.anchors[3 * a + 1] - p[1],
                      dz = pr.anchors[3 * a + 2] - p[2];
-        const double rd = sqrt(dx * dx + dy * dy + dz * dz) - sc.R(a);
+        double d, invd;
+        kf_sqrt_rsqrt(dx * dx + dy * dy + dz * dz, d, invd);
+        const double rd = d - sc.R(a);
         sse += rd * rd;
-    }
+    });
     return sse;
 }
 
 /* Gauss-Newton loop of MLLocation.cpp:164-225. p: seed in, estimate out. Requires sc.w = 1/e.
  * Returns the iteration count; sse_out = estimationError at the result. With n_used < 4 the
  * seed is returned untouched (MLLocation.cpp:158-161). The step p - Hs^-1 g equals the
- * reference's solve(Hs, Hs p - g). */
-KFPOS_HD inline int ml_estimate(double p[3], const Scratch &sc, const Params &pr, uint64_t drop,
+ * reference's solve(Hs, Hs p - g). One sweep per pass yields the cost of the point just reached
+ * and the gradient/Hessian for the next step (the reference evaluates them in two passes). */
+template <class SC>
+KFPOS_FN int ml_estimate(double p[3], const SC &sc, const Params &pr, uint64_t drop,
                                 int n_used, double &sse_out) {
     if (n_used < 4) {
         sse_out = (n_used == 0) ? -1.0 : ml_sse(p, sc, pr, drop);
@@ -218,17 +300,16 @@ KFPOS_HD inline int ml_estimate(double p[3], const Scratch &sc, const Params &pr
     }
     double cost = 1e20, newCost = 1.0, cw, sse, g[3], hs[6], c[6];
     int iter = 0;
-    ml_sweep(p, sc, pr, drop, cw, sse, g, hs);
-    while ((fabs(cost - newCost) / cost > 1e-3) && (iter < 10000)) {
+    for (;;) {
+        ml_sweep(p, sc, pr, drop, cw, sse, g, hs);
+        if (iter > 0) newCost = cw;
+        if (!((fabs(cost - newCost) / cost > 1e-3) && (iter < 10000))) break; /* MLLocation.cpp:168 */
         iter += 1;
         cost = newCost;
-        const double det = sym3_cofactors(hs, c);
-        const double idet = 1.0 / det;
+        const double idet = kf_rcp(sym3_cofactors(hs, c));
         p[0] -= (c[0] * g[0] + c[1] * g[1] + c[2] * g[2]) * idet;
         p[1] -= (c[1] * g[0] + c[3] * g[1] + c[4] * g[2]) * idet;
         p[2] -= (c[2] * g[0] + c[4] * g[1] + c[5] * g[2]) * idet;
-        ml_sweep(p, sc, pr, drop, cw, sse, g, hs);
-        newCost = cw;
     }
     sse_out = sse;
     return iter;
@@ -236,50 +317,57 @@ KFPOS_HD inline int ml_estimate(double p[3], const Scratch &sc, const Params &pr
 
 /* covariance of the ML estimate, inv(J' diag(max(e, e_ML))^-1 J) (MLLocation.cpp:229-252);
  * symmetric 3x3 packed. Only the ML initialisation uses it. */
-KFPOS_HD inline void ml_covariance(const double p[3], const Scratch &sc, const Params &pr, double sse,
+template <class SC>
+KFPOS_FN void ml_covariance(const double p[3], const SC &sc, const Params &pr, double sse,
                                    double cov[6]) {
-    double m[6] = {0, 0, 0, 0, 0, 0}, c[6];
-    for (int a = 0; a < pr.n_anchors; ++a) {
-        if (!used(sc, a, 0)) continue;
+    double m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0, c[6];
+    for_anchors<SC>(pr, [&](int a) {
+        if (!used(sc, a, 0)) return;
         const double dx = p[0] - pr.anchors[3 * a], dy = p[1] - pr.anchors[3 * a + 1],
                      dz = p[2] - pr.anchors[3 * a + 2];
         const double invd = 1.0 / sqrt(dx * dx + dy * dy + dz * dz);
         const double w = 1.0 / stdmax(sc.E(a), sse);
         const double gx = dx * invd, gy = dy * invd, gz = dz * invd;
-        m[0] += w * gx * gx; m[1] += w * gx * gy; m[2] += w * gx * gz;
-        m[3] += w * gy * gy; m[4] += w * gy * gz; m[5] += w * gz * gz;
-    }
+        m0 += w * gx * gx; m1 += w * gx * gy; m2 += w * gx * gz;
+        m3 += w * gy * gy; m4 += w * gy * gz; m5 += w * gz * gz;
+    });
+    const double m[6] = {m0, m1, m2, m3, m4, m5};
     const double idet = 1.0 / sym3_cofactors(m, c);
     KFPOS_UNROLL
     for (int k = 0; k < 6; ++k) cov[k] = c[k] * idet;
 }
 
-KFPOS_HD inline void set_weights_ml(const Scratch &sc, int A) {
-    for (int a = 0; a < A; ++a) sc.setW(a, 1.0 / sc.E(a));
+template <class SC>
+KFPOS_FN void set_weights_ml(SC &sc, const Params &pr) {
+    for_anchors<SC>(pr, [&](int a) { sc.setW(a, kf_rcp(sc.E(a))); });
 }
-KFPOS_HD inline void set_weights_iekf(const Scratch &sc, int A, double e_ml) {
-    for (int a = 0; a < A; ++a) sc.setW(a, 1.0 / stdmax(e_ml, sc.E(a))); /* KalmanFilterTOA.cpp:281 */
+template <class SC>
+KFPOS_FN void set_weights_iekf(SC &sc, const Params &pr, double e_ml) {
+    for_anchors<SC>(pr, [&](int a) { sc.setW(a, kf_rcp(stdmax(e_ml, sc.E(a)))); }); /* KalmanFilterTOA.cpp:281 */
 }
 
 /* Top-N composition (BASELINE config 5; MLLocation.cpp:284-300, 325-339): rank the residual^2
  * at the ML position of all ranges, drop the min(n-4, N) largest. Returns the drop mask. */
-KFPOS_HD inline uint64_t topn_mask(const double seed[3], const Scratch &sc, const Params &pr, int n_valid) {
+template <class SC>
+KFPOS_FN uint64_t topn_mask(const double seed[3], SC &sc, const Params &pr, int n_valid) {
     int ndrop = n_valid - 4 < pr.top_n ? n_valid - 4 : pr.top_n;
     if (ndrop <= 0) return 0;
     double p[3] = {seed[0], seed[1], seed[2]}, sse;
-    set_weights_ml(sc, pr.n_anchors);
+    set_weights_ml(sc, pr);
     ml_estimate(p, sc, pr, 0, n_valid, sse);
     uint64_t drop = 0;
     for (int k = 0; k < ndrop; ++k) {
         double worst = -1.0;
         int wi = -1;
-        for (int a = 0; a < pr.n_anchors; ++a) {
-            if (!used(sc, a, drop)) continue;
+        for_anchors<SC>(pr, [&](int a) {
+            if (!used(sc, a, drop)) return;
             const double dx = pr.anchors[3 * a] - p[0], dy = pr.anchors[3 * a + 1] - p[1],
                          dz = pr.anchors[3 * a + 2] - p[2];
-            const double rd = sqrt(dx * dx + dy * dy + dz * dz) - sc.R(a);
+            double d, invd;
+            kf_sqrt_rsqrt(dx * dx + dy * dy + dz * dz, d, invd);
+            const double rd = d - sc.R(a);
             if (rd * rd > worst) { worst = rd * rd; wi = a; }
-        }
+        });
         if (wi < 0) break;
         drop |= 1ull << wi;
     }
@@ -296,7 +384,7 @@ struct Tag6 {
 /* x <- F x is the identity on position (velocity restarts at 0); P <- F P F' + Q.
  * KalmanFilterTOA.cpp:115-123, 362-391. */
 template <bool SYMM>
-KFPOS_HD inline void predict6(Cov<6, SYMM> &P, double t, double accel_noise) {
+KFPOS_FN void predict6(Cov<6, SYMM> &P, double t, double accel_noise) {
     const double t2 = (t * t) / 2, a2 = accel_noise * accel_noise;
     KFPOS_UNROLL
     for (int i = 0; i < 3; ++i) {
@@ -333,20 +421,20 @@ struct Iekf6Out {
 
 /* kalmanStep3DIgnoreAnchor (KalmanFilterTOA.cpp:242-338) up to, not including, the covariance
  * update. xhat_p: predicted position; P: predicted covariance; drop: ignored anchors. */
-template <bool SYMM>
-KFPOS_HD inline void iekf6(const double xhat_p[3], const Cov<6, SYMM> &P, const Scratch &sc,
+template <bool SYMM, class SC>
+KFPOS_FN void iekf6(const double xhat_p[3], const Cov<6, SYMM> &P, SC &sc,
                            const Params &pr, uint64_t drop, int n_used, int max_steps, double tol,
                            Iekf6Out &o) {
     o.flags = (n_used < 4) ? ST_FEW_RANGES : 0u;
     /* ML position -> observation covariance (KalmanFilterTOA.cpp:268-282) */
     double pml[3] = {xhat_p[0], xhat_p[1], xhat_p[2]}, e_ml;
-    set_weights_ml(sc, pr.n_anchors);
+    set_weights_ml(sc, pr);
     o.ml_iters = ml_estimate(pml, sc, pr, drop, n_used, e_ml);
     if (isnan(pml[0]) || isnan(pml[1]) || isnan(pml[2])) {
         o.flags |= ST_ML_FALLBACK;
         e_ml = (n_used == 0) ? -1.0 : ml_sse(xhat_p, sc, pr, drop);
     }
-    set_weights_iekf(sc, pr.n_anchors, e_ml);
+    set_weights_iekf(sc, pr, e_ml);
 
     double p[3] = {xhat_p[0], xhat_p[1], xhat_p[2]};
     double dp[3] = {0.0, 0.0, 0.0}; /* delta_p = xhat_p - p */
@@ -356,21 +444,23 @@ KFPOS_HD inline void iekf6(const double xhat_p[3], const Cov<6, SYMM> &P, const 
     for (int k = 0; k < 6; ++k) o.mlast[k] = 0.0;
     o.gain_iters = 0;
     for (int iter = 0; iter < max_steps; ++iter) {
-        double c = qd, m[6] = {0, 0, 0, 0, 0, 0}, u[3] = {0, 0, 0};
-        for (int a = 0; a < pr.n_anchors; ++a) {
-            if (!used(sc, a, drop)) continue;
+        double c = qd, m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0, u0 = 0, u1 = 0, u2 = 0;
+        for_anchors<SC>(pr, [&](int a) {
+            if (!used(sc, a, drop)) return;
             const double dx = p[0] - pr.anchors[3 * a], dy = p[1] - pr.anchors[3 * a + 1],
                          dz = p[2] - pr.anchors[3 * a + 2];
-            const double d = sqrt(dx * dx + dy * dy + dz * dz);
-            const double w = sc.W(a), y = sc.R(a) - d, invd = 1.0 / d;
+            double d, invd;
+            kf_sqrt_rsqrt(dx * dx + dy * dy + dz * dz, d, invd);
+            const double w = sc.W(a), y = sc.R(a) - d;
             c += y * y * w;
             const double gx = dx * invd, gy = dy * invd, gz = dz * invd;
             const double v = (y - (gx * dp[0] + gy * dp[1] + gz * dp[2])) * w;
-            u[0] += gx * v; u[1] += gy * v; u[2] += gz * v;
+            u0 += gx * v; u1 += gy * v; u2 += gz * v;
             const double wx = w * gx, wy = w * gy, wz = w * gz;
-            m[0] += wx * gx; m[1] += wx * gy; m[2] += wx * gz;
-            m[3] += wy * gy; m[4] += wy * gz; m[5] += wz * gz;
-        }
+            m0 += wx * gx; m1 += wx * gy; m2 += wx * gz;
+            m3 += wy * gy; m4 += wy * gz; m5 += wz * gz;
+        });
+        const double m[6] = {m0, m1, m2, m3, m4, m5}, u[3] = {u0, u1, u2};
         if (fabs(cost - c) / cost < tol) break; /* KalmanFilterTOA.cpp:307 */
         cost = c;
         KFPOS_UNROLL
@@ -384,7 +474,7 @@ KFPOS_HD inline void iekf6(const double xhat_p[3], const Cov<6, SYMM> &P, const 
             for (int j = 0; j < 3; ++j)
                 a33[3 * i + j] = (i == j ? 1.0 : 0.0) + mm[i][0] * P(0, j) + mm[i][1] * P(1, j) + mm[i][2] * P(2, j);
         }
-        const double idet = 1.0 / gen3_adjugate(a33, adj);
+        const double idet = kf_rcp(gen3_adjugate(a33, adj));
         double w3[3];
         KFPOS_UNROLL
         for (int i = 0; i < 3; ++i) w3[i] = (adj[3 * i] * u[0] + adj[3 * i + 1] * u[1] + adj[3 * i + 2] * u[2]) * idet;
@@ -404,7 +494,7 @@ KFPOS_HD inline void iekf6(const double xhat_p[3], const Cov<6, SYMM> &P, const 
 
 /* P <- (I - K H) P = P - P[:,0:3] N P[0:3,:], N = (I + M Ppp)^-1 M (KalmanFilterTOA.cpp:326) */
 template <bool SYMM>
-KFPOS_HD inline void cov_update6(Cov<6, SYMM> &P, const double m[6]) {
+KFPOS_FN void cov_update6(Cov<6, SYMM> &P, const double m[6]) {
     const double mm[3][3] = {{m[0], m[1], m[2]}, {m[1], m[3], m[4]}, {m[2], m[4], m[5]}};
     double a33[9], adj[9], nn[3][3];
     KFPOS_UNROLL
@@ -413,7 +503,7 @@ KFPOS_HD inline void cov_update6(Cov<6, SYMM> &P, const double m[6]) {
         for (int j = 0; j < 3; ++j)
             a33[3 * i + j] = (i == j ? 1.0 : 0.0) + mm[i][0] * P(0, j) + mm[i][1] * P(1, j) + mm[i][2] * P(2, j);
     }
-    const double idet = 1.0 / gen3_adjugate(a33, adj);
+    const double idet = kf_rcp(gen3_adjugate(a33, adj));
     KFPOS_UNROLL
     for (int i = 0; i < 3; ++i) {
         KFPOS_UNROLL
@@ -442,15 +532,14 @@ KFPOS_HD inline void cov_update6(Cov<6, SYMM> &P, const double m[6]) {
 
 /* KalmanFilterTOA::estimatePositionKF (KalmanFilterTOA.cpp:70-156) for one tag and one epoch.
  * sc holds the epoch (r in metres, e). Returns the status word. */
-template <bool SYMM>
-KFPOS_HD inline uint32_t step_toa6(Tag6<SYMM> &tg, const Scratch &sc, const Params &pr, double dt) {
-    const int A = pr.n_anchors;
-    int n_valid = count_used(sc, A, 0);
+template <bool SYMM, class SC>
+KFPOS_FN uint32_t step_toa6(Tag6<SYMM> &tg, SC &sc, const Params &pr, double dt) {
+    int n_valid = count_used(sc, pr, 0);
     if (!pr.use_init_pos && (isnan(tg.pos[0]) || isnan(tg.pos[1]) || isnan(tg.pos[2]))) {
         /* ML initialisation, KalmanFilterTOA.cpp:90-108 (only the COV_FULL layout gets here) */
         if (n_valid < 4) return ST_FEW_RANGES;
         double p[3] = {1.0, 1.0, 4.0}, sse, c[6];
-        set_weights_ml(sc, A);
+        set_weights_ml(sc, pr);
         const int it = ml_estimate(p, sc, pr, 0, n_valid, sse);
         ml_covariance(p, sc, pr, sse, c);
         tg.pos[0] = p[0]; tg.pos[1] = p[1]; tg.pos[2] = p[2];
@@ -467,27 +556,36 @@ KFPOS_HD inline uint32_t step_toa6(Tag6<SYMM> &tg, const Scratch &sc, const Para
     uint64_t drop = 0;
     if (pr.top_n > 0 && !(isnan(tg.pos[0]) || isnan(tg.pos[1]) || isnan(tg.pos[2]))) {
         drop = topn_mask(tg.pos, sc, pr, n_valid);
-        n_valid = count_used(sc, A, drop);
+        n_valid = count_used(sc, pr, drop);
     }
     predict6(tg.P, dt, pr.accel_noise);
     const double xhat_p[3] = {tg.pos[0], tg.pos[1], tg.pos[2]};
 
+    /* kalmanStep3DCanIgnoreAnAnchor (KalmanFilterTOA.cpp:185-238) runs one solve with every range and
+     * one per left-out range, then adopts the left-out solve with the largest r_i - |p_(-i) - b_i| if
+     * that is positive and lowers the cost by more than the threshold. Here: phase 0 = all ranges,
+     * phase 1 = the leave-one-out sweep, phase 2 = the adopted set solved once more for its
+     * covariance (same arithmetic, so the same result). Without the heuristic only phase 2 runs.
+     * One call site keeps a single inlined copy of the solver in the kernel. */
     Iekf6Out o;
     int ignored = -1;
     uint64_t chosen = drop;
-    if (n_valid > 4 && pr.ignore_worst) {
-        /* kalmanStep3DCanIgnoreAnAnchor, KalmanFilterTOA.cpp:185-238: one solve with every range,
-         * one per left-out range; the winner is then re-solved for its covariance. */
-        iekf6(xhat_p, tg.P, sc, pr, drop, n_valid, 10, 1e-3, o);
-        const double cost_all = o.cost;
-        double max_distance = 0.0, worst_cost = 0.0;
-        int best_a = -1, best_i = -1, i = 0;
-        for (int a = 0; a < A; ++a) {
-            if (!used(sc, a, drop)) continue;
-            iekf6(xhat_p, tg.P, sc, pr, drop | (1ull << a), n_valid - 1, 10, 1e-3, o);
+    const int A = SC::NA > 0 ? SC::NA : pr.n_anchors;
+    const bool heuristic = n_valid > 4 && pr.ignore_worst;
+    int phase = heuristic ? 0 : 2, a = -1, i = 0, best_a = -1, best_i = -1;
+    double cost_all = 0.0, max_distance = 0.0, worst_cost = 0.0, ra = 0.0;
+    for (;;) {
+        const uint64_t mask = (phase == 1) ? (drop | (1ull << a)) : (phase == 2 ? chosen : drop);
+        const int n_use = (phase == 1) ? n_valid - 1 : (phase == 2 && ignored >= 0 ? n_valid - 1 : n_valid);
+        iekf6(xhat_p, tg.P, sc, pr, mask, n_use, 10, 1e-3, o);
+        if (phase == 2) break;
+        if (phase == 0) {
+            cost_all = o.cost;
+            phase = 1;
+        } else {
             const double dx = pr.anchors[3 * a] - o.p[0], dy = pr.anchors[3 * a + 1] - o.p[1],
                          dz = pr.anchors[3 * a + 2] - o.p[2];
-            const double diff = sc.R(a) - sqrt(dx * dx + dy * dy + dz * dz);
+            const double diff = ra - sqrt(dx * dx + dy * dy + dz * dz);
             if (i == 0 || diff > max_distance) {
                 max_distance = diff;
                 worst_cost = o.cost;
@@ -496,13 +594,19 @@ KFPOS_HD inline uint32_t step_toa6(Tag6<SYMM> &tg, const Scratch &sc, const Para
             }
             ++i;
         }
-        if (max_distance > 0.0 && (cost_all - worst_cost) > pr.cost_threshold) {
-            chosen = drop | (1ull << best_a);
-            ignored = best_i;
-            n_valid -= 1;
+        /* next range that is present */
+        for (++a; a < A; ++a) {
+            ra = sc.Rdyn(a);
+            if (!((drop >> a) & 1ull) && ra > 0.0) break;
+        }
+        if (a >= A) {
+            if (max_distance > 0.0 && (cost_all - worst_cost) > pr.cost_threshold) {
+                chosen = drop | (1ull << best_a);
+                ignored = best_i;
+            }
+            phase = 2;
         }
     }
-    iekf6(xhat_p, tg.P, sc, pr, chosen, n_valid, 10, 1e-3, o);
     cov_update6(tg.P, o.mlast);
     tg.pos[0] = o.p[0]; tg.pos[1] = o.p[1]; tg.pos[2] = o.p[2];
     return pack_status(o.flags, o.gain_iters, o.ml_iters, ignored);
@@ -510,7 +614,7 @@ KFPOS_HD inline uint32_t step_toa6(Tag6<SYMM> &tg, const Scratch &sc, const Para
 
 /* getPose (KalmanFilterTOA.cpp:438-473): predict-only; position block of F P F' + Q */
 template <bool SYMM>
-KFPOS_HD inline void pose6(const Tag6<SYMM> &tg, double t, double accel_noise, double pos[3], double cov[9]) {
+KFPOS_FN void pose6(const Tag6<SYMM> &tg, double t, double accel_noise, double pos[3], double cov[9]) {
     const double t2 = (t * t) / 2, a2 = accel_noise * accel_noise;
     KFPOS_UNROLL
     for (int i = 0; i < 3; ++i) {
@@ -534,13 +638,13 @@ struct Imu {
 };
 
 /* Sigma (row-major 3x3, symmetric positive definite) -> Ci with Sigma^-1 = Ci' Ci */
-KFPOS_HD inline void imu_whitener(const double s[9], double ci[6]) {
-    const double c00 = sqrt(s[0]);
-    const double c10 = s[3] / c00, c20 = s[6] / c00;
-    const double c11 = sqrt(s[4] - c10 * c10);
-    const double c21 = (s[7] - c20 * c10) / c11;
-    const double c22 = sqrt(s[8] - c20 * c20 - c21 * c21);
-    const double i00 = 1.0 / c00, i11 = 1.0 / c11, i22 = 1.0 / c22;
+KFPOS_FN void imu_whitener(const double s[9], double ci[6]) {
+    double c00, c11, c22, i00, i11, i22;
+    kf_sqrt_rsqrt(s[0], c00, i00);
+    const double c10 = s[3] * i00, c20 = s[6] * i00;
+    kf_sqrt_rsqrt(s[4] - c10 * c10, c11, i11);
+    const double c21 = (s[7] - c20 * c10) * i11;
+    kf_sqrt_rsqrt(s[8] - c20 * c20 - c21 * c21, c22, i22);
     const double i10 = -c10 * i00 * i11;
     const double i21 = -c21 * i11 * i22;
     const double i20 = -(c20 * i00 + c21 * i10) * i22;
@@ -548,7 +652,7 @@ KFPOS_HD inline void imu_whitener(const double s[9], double ci[6]) {
 }
 
 /* KalmanFilterTOAIMU.cpp:170-180, 392-421 */
-KFPOS_HD inline void predict9(Cov<9, true> &P, double t, double jolt) {
+KFPOS_FN void predict9(Cov<9, true> &P, double t, double jolt) {
     const double c = t * t / 2;
     /* blocks: p = 0..2, v = 3..5, a = 6..8; each block is updated from not-yet-overwritten ones */
     KFPOS_UNROLL
@@ -609,7 +713,7 @@ struct Factor9 {
     double lr[6], ilr[3]; /* chol3_psd of M_r */
     double la[6];         /* upper {00,01,02,11,12,22}: la(k,l) = a_k * ci(l,k) */
 };
-KFPOS_HD inline void factor9(const double mr[6], const double acc[3], const Imu &imu, Factor9 &f) {
+KFPOS_FN void factor9(const double mr[6], const double acc[3], const Imu &imu, Factor9 &f) {
     chol3_psd(mr, f.lr, f.ilr);
     if (imu.has) {
         f.la[0] = acc[0] * imu.ci[0]; f.la[1] = acc[0] * imu.ci[1]; f.la[2] = acc[0] * imu.ci[2];
@@ -621,7 +725,7 @@ KFPOS_HD inline void factor9(const double mr[6], const double acc[3], const Imu 
     }
 }
 /* dense access L(k,l), k,l in 0..5 (compile-time indices) */
-KFPOS_HD inline double L9(const Factor9 &f, int k, int l) {
+KFPOS_FN double L9(const Factor9 &f, int k, int l) {
     if (k < 3 && l < 3) {
         if (k < l) return 0.0;
         /* lower packed {00,10,20,11,21,22} */
@@ -644,7 +748,8 @@ struct Iekf9Out {
 };
 
 /* kalmanStep3D (KalmanFilterTOAIMU.cpp:242-340, with the 3-token repair) up to the covariance update */
-KFPOS_HD inline void iekf9(const double xhat[9], const Cov<9, true> &P, const Scratch &sc, const Params &pr,
+template <class SC>
+KFPOS_FN void iekf9(const double xhat[9], const Cov<9, true> &P, SC &sc, const Params &pr,
                            bool has_ranging, int n_used, const Imu &imu, int max_steps, double tol,
                            Iekf9Out &o) {
     const uint64_t drop = has_ranging ? 0ull : ~0ull;
@@ -653,9 +758,9 @@ KFPOS_HD inline void iekf9(const double xhat[9], const Cov<9, true> &P, const Sc
     o.ml_iters = 0;
     if (has_ranging) {
         double pml[3] = {xhat[0], xhat[1], xhat[2]}, e_ml;
-        set_weights_ml(sc, pr.n_anchors);
+        set_weights_ml(sc, pr);
         o.ml_iters = ml_estimate(pml, sc, pr, drop, n_used, e_ml); /* no NaN fallback in this filter */
-        set_weights_iekf(sc, pr.n_anchors, e_ml);
+        set_weights_iekf(sc, pr, e_ml);
     }
     double p[3] = {xhat[0], xhat[1], xhat[2]}, acc[3] = {xhat[6], xhat[7], xhat[8]};
     double de[6] = {0, 0, 0, 0, 0, 0}; /* delta on the updated components (position, acceleration) */
@@ -666,21 +771,23 @@ KFPOS_HD inline void iekf9(const double xhat[9], const Cov<9, true> &P, const Sc
     o.dlast[0] = o.dlast[1] = o.dlast[2] = 0.0;
     o.gain_iters = 0;
     for (int iter = 0; iter < max_steps; ++iter) {
-        double c = qd, m[6] = {0, 0, 0, 0, 0, 0}, u[3] = {0, 0, 0};
-        for (int a = 0; a < pr.n_anchors; ++a) {
-            if (!used(sc, a, drop)) continue;
+        double c = qd, m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0, u0 = 0, u1 = 0, u2 = 0;
+        for_anchors<SC>(pr, [&](int a) {
+            if (!used(sc, a, drop)) return;
             const double dx = p[0] - pr.anchors[3 * a], dy = p[1] - pr.anchors[3 * a + 1],
                          dz = p[2] - pr.anchors[3 * a + 2];
-            const double d = sqrt(dx * dx + dy * dy + dz * dz);
-            const double w = sc.W(a), y = sc.R(a) - d, invd = 1.0 / d;
+            double d, invd;
+            kf_sqrt_rsqrt(dx * dx + dy * dy + dz * dz, d, invd);
+            const double w = sc.W(a), y = sc.R(a) - d;
             c += y * y * w;
             const double gx = dx * invd, gy = dy * invd, gz = dz * invd;
             const double v = (y - (gx * de[0] + gy * de[1] + gz * de[2])) * w;
-            u[0] += gx * v; u[1] += gy * v; u[2] += gz * v;
+            u0 += gx * v; u1 += gy * v; u2 += gz * v;
             const double wx = w * gx, wy = w * gy, wz = w * gz;
-            m[0] += wx * gx; m[1] += wx * gy; m[2] += wx * gz;
-            m[3] += wy * gy; m[4] += wy * gz; m[5] += wz * gz;
-        }
+            m0 += wx * gx; m1 += wx * gy; m2 += wx * gz;
+            m3 += wy * gy; m4 += wy * gz; m5 += wz * gz;
+        });
+        const double m[6] = {m0, m1, m2, m3, m4, m5}, u[3] = {u0, u1, u2};
         double s[6] = {0, 0, 0, 0, 0, 0};
         if (imu.has) {
             /* y_a = z_a - a; cost += y_a' Sigma^-1 y_a = |Ci y_a|^2; s_a = Ci (y_a - D delta_a) */
@@ -743,7 +850,7 @@ KFPOS_HD inline void iekf9(const double xhat[9], const Cov<9, true> &P, const Sc
             double d = T(j, j);
             KFPOS_UNROLL
             for (int k = 0; k < j; ++k) d -= T(k, j) * T(k, j) * dinv[k]; /* T(k,j) holds (L D)(j,k) */
-            dinv[j] = 1.0 / d;
+            dinv[j] = kf_rcp(d);
             KFPOS_UNROLL
             for (int i = j + 1; i < 6; ++i) {
                 double v = T(j, i);
@@ -804,7 +911,7 @@ KFPOS_HD inline void iekf9(const double xhat[9], const Cov<9, true> &P, const Sc
 
 /* P <- (I - K H) P (KalmanFilterTOAIMU.cpp:338) as six rank-1 downdates along the columns of
  * E' L (unit-noise pseudo-measurements): P -= (P t)(P t)' / (1 + t' P t). */
-KFPOS_HD inline void cov_update9(Cov<9, true> &P, const double mr[6], const double d[3], const Imu &imu) {
+KFPOS_FN void cov_update9(Cov<9, true> &P, const double mr[6], const double d[3], const Imu &imu) {
     Factor9 f;
     factor9(mr, d, imu, f);
     KFPOS_UNROLL
@@ -825,7 +932,7 @@ KFPOS_HD inline void cov_update9(Cov<9, true> &P, const double mr[6], const doub
             const bool nz = (l < 3 && k < 3 && l >= k) || (l >= 3 && k >= 3 && l <= k);
             if (nz) s += L9(f, l, k) * pt[e9(l)];
         }
-        const double is = 1.0 / s;
+        const double is = kf_rcp(s);
         KFPOS_UNROLL
         for (int i = 0; i < 9; ++i) {
             const double pi = pt[i] * is;
@@ -837,15 +944,15 @@ KFPOS_HD inline void cov_update9(Cov<9, true> &P, const double mr[6], const doub
 
 /* KalmanFilterTOAIMU::estimatePositionKF (KalmanFilterTOAIMU.cpp:100-195) for one tag.
  * has_ranging = false is the IMU-only call of newIMUMeasurement (:91). */
-KFPOS_HD inline uint32_t step_imu9(Tag9 &tg, const Scratch &sc, const Params &pr, double dt,
+template <class SC>
+KFPOS_FN uint32_t step_imu9(Tag9 &tg, SC &sc, const Params &pr, double dt,
                                    bool has_ranging, const Imu &imu) {
-    const int A = pr.n_anchors;
-    const int n_valid = has_ranging ? count_used(sc, A, 0) : 0;
+    const int n_valid = has_ranging ? count_used(sc, pr, 0) : 0;
     if (!pr.use_init_pos && (isnan(tg.pos[0]) || isnan(tg.pos[1]))) { /* :121-122, z is not tested */
         if (!has_ranging) return 0;
         if (n_valid < 4) return ST_FEW_RANGES;
         double p[3] = {1.0, 1.0, 4.0}, sse, c[6];
-        set_weights_ml(sc, A);
+        set_weights_ml(sc, pr);
         const int it = ml_estimate(p, sc, pr, 0, n_valid, sse);
         ml_covariance(p, sc, pr, sse, c);
         tg.pos[0] = p[0]; tg.pos[1] = p[1]; tg.pos[2] = p[2];
@@ -870,7 +977,7 @@ KFPOS_HD inline uint32_t step_imu9(Tag9 &tg, const Scratch &sc, const Params &pr
 }
 
 /* getPose (KalmanFilterTOAIMU.cpp:476-510): predicted position / velocity and the position block */
-KFPOS_HD inline void pose9(const Tag9 &tg, double t, double jolt, double pos[3], double vel[3], double cov[9]) {
+KFPOS_FN void pose9(const Tag9 &tg, double t, double jolt, double pos[3], double vel[3], double cov[9]) {
     const double c = t * t / 2, t3 = (t * t * t) / 6;
     KFPOS_UNROLL
     for (int i = 0; i < 3; ++i) {

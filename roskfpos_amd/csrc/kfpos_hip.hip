@@ -26,6 +26,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -101,8 +102,20 @@ __device__ inline Scratch stage_epoch(const KArgs &a, double *lds, int lane, siz
     return sc;
 }
 
+/* epoch -> registers (anchor count fixed at compile time) */
+template <typename MREAL, int AS>
+__device__ inline void stage_epoch_regs(const KArgs &a, size_t t, RegScratch<AS> &sc) {
+#pragma unroll
+    for (int k = 0; k < AS; ++k) {
+        const int32_t mm = a.ranges[(size_t)k * a.T + t];
+        sc.r[k] = mm > 0 ? (double)mm / 1000 : 0.0; /* Posgenerator.cpp:483-484 */
+        sc.e[k] = ld<MREAL>(a.err, (size_t)k * a.T + t);
+        sc.w[k] = 0.0;
+    }
+}
+
 /* ------------------------------------------------------------------ 6-state step kernel */
-template <bool SYMM, typename REAL, typename MREAL>
+template <bool SYMM, typename REAL, typename MREAL, int AS>
 __global__ __launch_bounds__(WAVE) void k_step_toa6(const KArgs a) {
     extern __shared__ double lds[];
     const int lane = threadIdx.x;
@@ -110,7 +123,6 @@ __global__ __launch_bounds__(WAVE) void k_step_toa6(const KArgs a) {
     if (t >= (size_t)a.T) return;
     const size_t T = a.T;
     const Params pr = make_params(a);
-    const Scratch sc = stage_epoch<MREAL>(a, lds, lane, t);
 
     Tag6<SYMM> tg;
 #pragma unroll
@@ -119,7 +131,15 @@ __global__ __launch_bounds__(WAVE) void k_step_toa6(const KArgs a) {
     for (int k = 0; k < Cov<6, SYMM>::SZ; ++k) tg.P.a[k] = ld<REAL>(a.P, k * T + t);
     const double dt = a.dt ? a.dt[t] : a.dt_shared;
 
-    uint32_t s = step_toa6<SYMM>(tg, sc, pr, dt);
+    uint32_t s;
+    if constexpr (AS > 0) {
+        RegScratch<AS> sc;
+        stage_epoch_regs<MREAL, AS>(a, t, sc);
+        s = step_toa6<SYMM>(tg, sc, pr, dt);
+    } else {
+        Scratch sc = stage_epoch<MREAL>(a, lds, lane, t);
+        s = step_toa6<SYMM>(tg, sc, pr, dt);
+    }
 
     bool fin = true;
 #pragma unroll
@@ -139,7 +159,7 @@ __global__ __launch_bounds__(WAVE) void k_step_toa6(const KArgs a) {
 }
 
 /* ------------------------------------------------------------------ 9-state step kernel */
-template <typename REAL, typename MREAL>
+template <typename REAL, typename MREAL, int AS>
 __global__ __launch_bounds__(WAVE) void k_step_imu9(const KArgs a) {
     extern __shared__ double lds[];
     const int lane = threadIdx.x;
@@ -148,8 +168,6 @@ __global__ __launch_bounds__(WAVE) void k_step_imu9(const KArgs a) {
     const size_t T = a.T;
     const Params pr = make_params(a);
     const bool has_ranging = a.mode != MODE_IMU_ONLY;
-    Scratch sc{nullptr, nullptr, nullptr, WAVE};
-    if (has_ranging) sc = stage_epoch<MREAL>(a, lds, lane, t);
 
     uint32_t fl = a.flags[t];
     Imu imu;
@@ -195,7 +213,21 @@ __global__ __launch_bounds__(WAVE) void k_step_imu9(const KArgs a) {
     for (int k = 0; k < 45; ++k) tg.P.a[k] = ld<REAL>(a.P, k * T + t);
     const double dt = a.dt ? a.dt[t] : a.dt_shared;
 
-    uint32_t s = step_imu9(tg, sc, pr, dt, has_ranging, imu);
+    uint32_t s;
+    if constexpr (AS > 0) {
+        RegScratch<AS> sc;
+        if (has_ranging) {
+            stage_epoch_regs<MREAL, AS>(a, t, sc);
+        } else {
+#pragma unroll
+            for (int k = 0; k < AS; ++k) sc.r[k] = sc.e[k] = sc.w[k] = 0.0;
+        }
+        s = step_imu9(tg, sc, pr, dt, has_ranging, imu);
+    } else {
+        Scratch sc{nullptr, nullptr, nullptr, WAVE};
+        if (has_ranging) sc = stage_epoch<MREAL>(a, lds, lane, t);
+        s = step_imu9(tg, sc, pr, dt, has_ranging, imu);
+    }
 
     bool fin = true;
 #pragma unroll
@@ -293,6 +325,7 @@ struct kfpos_handle {
     int msz;      /* sizeof(kfpos_real): bytes per measurement element */
     int A;        /* anchors set */
     bool have_anchors, stepped;
+    bool force_generic; /* KFPOS_GENERIC_KERNEL=1: always the LDS-staged kernel (A/B measurements, tests) */
     double anchors[KFPOS_MAX_ANCHORS * 3];
     /* device state */
     double *d_pos = nullptr;
@@ -340,22 +373,46 @@ void fill_args(const kfpos_handle *h, KArgs &a) {
 
 typedef void (*step_kernel_t)(const KArgs);
 
+/* anchor-count specialisations: 8 (BASELINE configs 2-4) and 16 (config 5) keep the epoch in registers;
+ * every other count runs the generic LDS-staged kernel (AS = 0) */
+int static_anchors(const kfpos_handle *h) {
+    const int A = h->cfg.max_anchors;
+    if (A == 8) return 8;
+    if (A == 16 && h->cfg.model == KFPOS_MODEL_TOA) return 16;
+    return 0;
+}
+
+template <bool SYMM, typename REAL, typename MREAL>
+step_kernel_t toa6_kernel(int as) {
+    if (as == 8) return k_step_toa6<SYMM, REAL, MREAL, 8>;
+    if (as == 16) return k_step_toa6<SYMM, REAL, MREAL, 16>;
+    return k_step_toa6<SYMM, REAL, MREAL, 0>;
+}
+template <typename REAL, typename MREAL>
+step_kernel_t imu9_kernel(int as) {
+    if (as == 8) return k_step_imu9<REAL, MREAL, 8>;
+    return k_step_imu9<REAL, MREAL, 0>;
+}
+
 step_kernel_t step_kernel(const kfpos_handle *h) {
-    const int st = h->cfg.storage;
+    const int st = h->cfg.storage, as = h->force_generic ? 0 : static_anchors(h);
     if (h->cfg.model == KFPOS_MODEL_TOA) {
         if (h->full)
-            return st == KFPOS_STORE_F32 ? k_step_toa6<false, float, float>
-                 : st == KFPOS_STORE_MIXED ? k_step_toa6<false, double, float> : k_step_toa6<false, double, double>;
-        return st == KFPOS_STORE_F32 ? k_step_toa6<true, float, float>
-             : st == KFPOS_STORE_MIXED ? k_step_toa6<true, double, float> : k_step_toa6<true, double, double>;
+            return st == KFPOS_STORE_F32 ? toa6_kernel<false, float, float>(as)
+                 : st == KFPOS_STORE_MIXED ? toa6_kernel<false, double, float>(as)
+                                           : toa6_kernel<false, double, double>(as);
+        return st == KFPOS_STORE_F32 ? toa6_kernel<true, float, float>(as)
+             : st == KFPOS_STORE_MIXED ? toa6_kernel<true, double, float>(as)
+                                       : toa6_kernel<true, double, double>(as);
     }
-    return st == KFPOS_STORE_F32 ? k_step_imu9<float, float>
-         : st == KFPOS_STORE_MIXED ? k_step_imu9<double, float> : k_step_imu9<double, double>;
+    return st == KFPOS_STORE_F32 ? imu9_kernel<float, float>(as)
+         : st == KFPOS_STORE_MIXED ? imu9_kernel<double, float>(as) : imu9_kernel<double, double>(as);
 }
 
 int launch_step(kfpos_handle *h, const KArgs &a, hipStream_t s) {
     const int blocks = (h->cfg.n_tags + WAVE - 1) / WAVE;
-    const size_t lds = (a.mode == MODE_IMU_ONLY) ? 0 : lds_bytes(h);
+    const bool generic = h->force_generic || static_anchors(h) == 0;
+    const size_t lds = (a.mode == MODE_IMU_ONLY || !generic) ? 0 : lds_bytes(h);
     hipLaunchKernelGGL(step_kernel(h), dim3(blocks), dim3(WAVE), lds, s, a);
     HIPCHK(hipGetLastError());
     h->stepped = true;
@@ -453,6 +510,10 @@ int kfpos_create(const kfpos_config *cfg, kfpos_handle **out) {
     h->A = 0;
     h->have_anchors = false;
     h->stepped = false;
+    {
+        const char *g = getenv("KFPOS_GENERIC_KERNEL");
+        h->force_generic = g && g[0] == '1';
+    }
     std::memset(h->anchors, 0, sizeof(h->anchors));
     const size_t T = cfg->n_tags, A = cfg->max_anchors, r = h->rsz, m = h->msz;
 #define ALLOC(ptr, bytes)                                                     \

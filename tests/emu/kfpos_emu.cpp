@@ -19,6 +19,7 @@ using namespace kfpos;
 
 struct kfe_bank {
     int model, T, A, full; /* full: COV_FULL layout (6-state ML-init mode) */
+    int use_static = 0;    /* run the anchor-count-specialised (register-resident epoch) code path */
     Params pr;
     std::vector<double> anchors;
     std::vector<Tag6<true>> t6s;
@@ -73,6 +74,7 @@ kfe_bank *kfe_create(int model, int n_tags, int n_anchors, const double *anchors
     return b;
 }
 void kfe_destroy(kfe_bank *b) { delete b; }
+void kfe_set_static(kfe_bank *b, int on) { b->use_static = on; }
 
 static void fill_scratch(const kfe_bank *b, const int32_t *mm, const double *err, std::vector<double> &buf,
                          Scratch &sc) {
@@ -88,17 +90,41 @@ static void fill_scratch(const kfe_bank *b, const int32_t *mm, const double *err
     }
 }
 
+} // extern "C"
+
+template <int AS>
+static uint32_t step_static(kfe_bank *b, int t, const int32_t *mm, const double *err, double lag) {
+    RegScratch<AS> sc;
+    for (int a = 0; a < AS; ++a) {
+        sc.r[a] = mm[a] > 0 ? (double)mm[a] / 1000 : 0.0;
+        sc.e[a] = err[a];
+        sc.w[a] = 0.0;
+    }
+    if (b->model == 0 && !b->full) return step_toa6(b->t6s[t], sc, b->pr, lag);
+    if (b->model == 0) return step_toa6(b->t6f[t], sc, b->pr, lag);
+    return step_imu9(b->t9[t], sc, b->pr, lag, true, b->imu[t]);
+}
+
+extern "C" {
+
 void kfe_step_toa(kfe_bank *b, const int32_t *range_mm, const double *err_est, const double *dt, int dt_len,
                   uint32_t *status) {
     std::vector<double> buf;
     Scratch sc;
     for (int t = 0; t < b->T; ++t) {
-        fill_scratch(b, range_mm + (size_t)t * b->A, err_est + (size_t)t * b->A, buf, sc);
+        const int32_t *mm = range_mm + (size_t)t * b->A;
+        const double *err = err_est + (size_t)t * b->A;
         const double lag = dt[dt_len > 1 ? t : 0];
         uint32_t st;
-        if (b->model == 0 && !b->full) st = step_toa6(b->t6s[t], sc, b->pr, lag);
-        else if (b->model == 0) st = step_toa6(b->t6f[t], sc, b->pr, lag);
-        else st = step_imu9(b->t9[t], sc, b->pr, lag, true, b->imu[t]);
+        if (b->use_static && b->A == 8) st = step_static<8>(b, t, mm, err, lag);
+        else if (b->use_static && b->A == 16) st = step_static<16>(b, t, mm, err, lag);
+        else if (b->use_static && b->A == 4) st = step_static<4>(b, t, mm, err, lag);
+        else {
+            fill_scratch(b, mm, err, buf, sc);
+            if (b->model == 0 && !b->full) st = step_toa6(b->t6s[t], sc, b->pr, lag);
+            else if (b->model == 0) st = step_toa6(b->t6f[t], sc, b->pr, lag);
+            else st = step_imu9(b->t9[t], sc, b->pr, lag, true, b->imu[t]);
+        }
         b->flags[t] |= FL_STARTED;
         if (status) status[t] = st;
     }

@@ -83,6 +83,7 @@ def emu_lib():
         L.kfe_create.argtypes = [C.c_int, C.c_int, C.c_int, dp, C.c_double, C.c_double, C.c_int, C.c_double,
                                  C.c_int, C.c_int, C.c_void_p]
         L.kfe_destroy.argtypes = [C.c_void_p]
+        L.kfe_set_static.argtypes = [C.c_void_p, C.c_int]
         L.kfe_step_toa.argtypes = [C.c_void_p, ip, dp, dp, C.c_int, C.c_void_p]
         L.kfe_step_imu.argtypes = [C.c_void_p, dp, dp, dp, C.c_int, C.c_void_p]
         L.kfe_latch_imu.argtypes = [C.c_void_p, dp, dp]
@@ -95,6 +96,8 @@ def emu_lib():
 class EmuImpl:
     """kfpos_core.h compiled for the host: the arithmetic the HIP kernels run, lane by lane."""
 
+    static = False  # True: the anchor-count-specialised code path (epoch in registers)
+
     def __init__(self, case, w, init):
         self.T, self.A, self.n = case.T, case.A, 9 if case.model == 1 else 6
         ipt = None if init is None else np.ascontiguousarray(init, dtype=np.float64)
@@ -102,6 +105,7 @@ class EmuImpl:
         self.h = emu_lib().kfe_create(case.model, case.T, case.A, np.ascontiguousarray(w.anchors), 0.5, 0.5,
                                       int(case.ignore_worst), 0.5, case.top_n, int(init is not None),
                                       None if ipt is None else ipt.ctypes.data)
+        emu_lib().kfe_set_static(self.h, int(self.static))
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -140,6 +144,10 @@ class EmuImpl:
         pos, cov, vel = np.zeros((self.T, 3)), np.zeros((self.T, 9)), np.zeros((self.T, 3))
         emu_lib().kfe_get_pose(self.h, dt_ahead, pos, cov, vel)
         return pos, cov.reshape(self.T, 3, 3), vel
+
+
+class EmuStaticImpl(EmuImpl):
+    static = True
 
 
 class GpuImpl:

@@ -9,17 +9,20 @@ import numpy as np
 import pytest
 
 from cases import CASES, CASE_BY_NAME, drive, rms_and_max
-from impls import EmuImpl, OracleImpl
+from impls import EmuImpl, EmuStaticImpl, OracleImpl
 
 # Bar from BASELINE.json: <= 1e-6 m RMS. Everything except the one documented case sits near 1e-12.
 TOL_RMS = {"toa6_A8_mlinit": 1e-6}
 TOL_DEFAULT_RMS, TOL_DEFAULT_MAX = 1e-9, 1e-8
 
 
+@pytest.mark.parametrize("impl", [EmuImpl, EmuStaticImpl], ids=["generic", "static"])
 @pytest.mark.parametrize("case", CASES, ids=[c.name for c in CASES])
-def test_kernel_math_matches_oracle(case):
+def test_kernel_math_matches_oracle(case, impl):
+    """generic = run-time anchor count, epoch staged per lane (LDS on the GPU); static = anchor count fixed at
+    compile time (4/8/16), epoch in registers, every anchor loop unrolled."""
     fo, po, so = drive(case, OracleImpl, record=True)
-    fe, pe, se = drive(case, EmuImpl, record=True)
+    fe, pe, se = drive(case, impl, record=True)
     rms, mx, same_nan = rms_and_max(pe, po)
     assert same_nan
     if case.name in TOL_RMS:

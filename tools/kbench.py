@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Step-kernel timings for the BASELINE configurations (device-resident traces, HIP events).
+
+    python tools/kbench.py [--steps 50] [--configs c2,c3,c4shard,c5,toa6_65k]
+
+Prints one line per configuration: us per launch, tag-steps/s, algorithmic GB/s (SURVEY 8d byte figures).
+Set KFPOS_GENERIC_KERNEL=1 to time the LDS-staged generic kernels instead of the anchor-count-specialised ones.
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from roskfpos_amd import capi  # noqa: E402
+from roskfpos_amd.synth import Workload  # noqa: E402
+
+CONFIGS = {
+    # name: (model, tags, anchors, storage, top_n, ignore_worst, algorithmic bytes per tag-step)
+    "c2": (0, 4096, 8, capi.STORE_F64, 0, False, 560),
+    "toa6_65k": (0, 65536, 8, capi.STORE_F64, 0, False, 560),
+    "c4shard": (0, 131072, 8, capi.STORE_F64, 0, False, 560),
+    "c3": (1, 65536, 8, capi.STORE_MIXED, 0, False, 544),
+    "c3_f32": (1, 65536, 8, capi.STORE_F32, 0, False, 544),
+    "c5": (0, 262144, 16, capi.STORE_F32, 2, False, 344),
+    "iw8": (0, 65536, 8, capi.STORE_F64, 0, True, 560),
+}
+
+
+def run(name, steps, warmup):
+    model, T, A, storage, top_n, iw, nbytes = CONFIGS[name]
+    w = Workload(T, A)
+    real = np.float64 if storage == capi.STORE_F64 else np.float32
+    S = steps + warmup
+    dev = "cuda:0"
+    ranges = torch.empty((S, A, T), dtype=torch.int32, device=dev)
+    accel = torch.empty((S, 3, T), dtype=torch.float32 if real == np.float32 else torch.float64, device=dev)
+    for s in range(S):
+        ranges[s].copy_(torch.from_numpy(np.ascontiguousarray(w.ranges_mm(s).T)))
+        if model == 1:
+            accel[s].copy_(torch.from_numpy(np.ascontiguousarray(w.accel(s, real).T)))
+    err = torch.from_numpy(np.ascontiguousarray(w.err_est(real).T)).to(dev)
+    cov = torch.from_numpy(np.ascontiguousarray(w.accel_cov(real).T)).to(dev)
+    dts = np.array([w.dt_of(s) for s in range(S)])
+    bank = capi.KfposBank(model, T, w.anchors, storage=storage, top_n=top_n, ignore_worst=iw,
+                          init_pos=w.init_positions())
+    stream = torch.cuda.current_stream().cuda_stream
+    status = torch.zeros(T, dtype=torch.int32, device=dev)
+
+    def go(s0, n):
+        kw = dict(accel=accel[s0], stride_accel=3 * T, cov=cov, stride_cov=0) if model == 1 else {}
+        bank.run_trace_dev(n, ranges[s0], A * T, err, 0, dts[s0:s0 + n], status=status, stream=stream, **kw)
+
+    go(0, warmup)
+    torch.cuda.synchronize()
+    bank.timing_begin(stream)
+    go(warmup, steps)
+    ms = bank.timing_end(stream)
+    us = ms * 1e3 / steps
+    st = status.cpu().numpy().astype(np.uint32)
+    x, _, _ = bank.get_state()
+    truth = w.position(w.time_of(S - 1))
+    out = {"config": name, "tags": T, "anchors": A, "us_per_launch": round(us, 2),
+           "tag_steps_per_s": T / us * 1e6, "algo_GBps": nbytes * T / us / 1e3,
+           "hbm_frac": nbytes * T / us / 1e3 / 8000.0,
+           "mean_gain_iters": float(((st >> 8) & 0xFF).mean()), "mean_ml_iters": float(((st >> 16) & 0xFF).mean()),
+           "max_gain_iters": int(((st >> 8) & 0xFF).max()),
+           "gain_iters_hist": np.bincount((st >> 8) & 0xFF, minlength=21).tolist(),
+           "frac_waves_with_max_lane": float((((st >> 8) & 0xFF).reshape(-1, 64).max(1) == ((st >> 8) & 0xFF).max()).mean()),
+           "mean_wave_max_gain": float(((st >> 8) & 0xFF).reshape(-1, 64).max(1).mean()),
+           "mean_wave_max_ml": float(((st >> 16) & 0xFF).reshape(-1, 64).max(1).mean()),
+           "rms_vs_truth": float(np.sqrt(((x[:, :3] - truth) ** 2).sum(1).mean())),
+           "generic": os.environ.get("KFPOS_GENERIC_KERNEL", "0")}
+    print(json.dumps(out), flush=True)
+    bank.close()
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--configs", default="c2,toa6_65k,c3,c5")
+    a = ap.parse_args()
+    for n in a.configs.split(","):
+        run(n, a.steps, a.warmup)
