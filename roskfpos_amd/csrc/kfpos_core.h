@@ -104,6 +104,21 @@ KFPOS_FN void kf_sqrt_rsqrt(double x, double &d, double &invd) {
 #endif
 }
 
+/* Integer millimetres -> metres with the value of the reference's `(double) mm / 1000`
+ * (Posgenerator.cpp:484), bit for bit: q = mm * RN(1/1000) is within one ulp, r = mm - 1000 q is exact
+ * in an fma, and q + r * RN(1/1000) rounds to the correctly rounded quotient (checked exhaustively for
+ * every mm < 2^26 and sampled to 2^31 against the division). 3 instructions instead of ~20. */
+KFPOS_FN double kf_mm_to_m(int32_t mm) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double x = (double)mm;
+    const double q = x * 0.001;
+    const double r = __builtin_fma(-q, 1000.0, x);
+    return __builtin_fma(r, 0.001, q);
+#else
+    return (double)mm / 1000;
+#endif
+}
+
 /* std::max as the reference uses it: (a < b) ? b : a (matters for NaN) */
 KFPOS_FN double stdmax(double a, double b) { return (a < b) ? b : a; }
 
@@ -243,15 +258,18 @@ KFPOS_FN void ml_sweep(const double p[3], const SC &sc, const Params &pr, uint64
     double cw_ = 0.0, sse_ = 0.0, g0 = 0.0, g1 = 0.0, g2 = 0.0;
     double h0 = 0.0, h1 = 0.0, h2 = 0.0, h3 = 0.0, h4 = 0.0, h5 = 0.0;
     for_anchors<SC>(pr, [&](int a) {
-        if (!used(sc, a, drop)) return;
-        const double r = sc.R(a), w = sc.W(a);
+        /* branch-free: an absent / dropped range gets weight 0 (select, so a garbage errorEstimation of a
+         * missing range never enters), which keeps the unrolled anchors in one basic block and lets the
+         * scheduler interleave their independent rsqrt chains */
+        const bool on = used(sc, a, drop);
+        const double r = sc.R(a), w = on ? sc.W(a) : 0.0;
         const double dx = pr.anchors[3 * a] - p[0], dy = pr.anchors[3 * a + 1] - p[1],
                      dz = pr.anchors[3 * a + 2] - p[2];
         double d, invd;
         kf_sqrt_rsqrt(dx * dx + dy * dy + dz * dz, d, invd);
         const double rd = r - d;
         cw_ += rd * rd * w;
-        sse_ += rd * rd;
+        sse_ += on ? rd * rd : 0.0;
         const double gi = rd * invd * w;
         g0 += gi * dx;
         g1 += gi * dy;
@@ -275,13 +293,12 @@ template <class SC>
 KFPOS_FN double ml_sse(const double p[3], const SC &sc, const Params &pr, uint64_t drop) {
     double sse = 0.0;
     for_anchors<SC>(pr, [&](int a) {
-        if (!used(sc, a, drop)) return;
         const double dx = pr.anchors[3 * a] - p[0], dy = pr.anchors[3 * a + 1] - p[1],
                      dz = pr.anchors[3 * a + 2] - p[2];
         double d, invd;
         kf_sqrt_rsqrt(dx * dx + dy * dy + dz * dz, d, invd);
         const double rd = d - sc.R(a);
-        sse += rd * rd;
+        sse += used(sc, a, drop) ? rd * rd : 0.0;
     });
     return sse;
 }
@@ -360,13 +377,14 @@ KFPOS_FN uint64_t topn_mask(const double seed[3], SC &sc, const Params &pr, int 
         double worst = -1.0;
         int wi = -1;
         for_anchors<SC>(pr, [&](int a) {
-            if (!used(sc, a, drop)) return;
             const double dx = pr.anchors[3 * a] - p[0], dy = pr.anchors[3 * a + 1] - p[1],
                          dz = pr.anchors[3 * a + 2] - p[2];
             double d, invd;
             kf_sqrt_rsqrt(dx * dx + dy * dy + dz * dz, d, invd);
             const double rd = d - sc.R(a);
-            if (rd * rd > worst) { worst = rd * rd; wi = a; }
+            const bool take = used(sc, a, drop) && (rd * rd > worst);
+            worst = take ? rd * rd : worst;
+            wi = take ? a : wi;
         });
         if (wi < 0) break;
         drop |= 1ull << wi;
@@ -419,14 +437,13 @@ struct Iekf6Out {
     uint32_t flags;
 };
 
-/* kalmanStep3DIgnoreAnchor (KalmanFilterTOA.cpp:242-338) up to, not including, the covariance
- * update. xhat_p: predicted position; P: predicted covariance; drop: ignored anchors. */
-template <bool SYMM, class SC>
-KFPOS_FN void iekf6(const double xhat_p[3], const Cov<6, SYMM> &P, SC &sc,
-                           const Params &pr, uint64_t drop, int n_used, int max_steps, double tol,
-                           Iekf6Out &o) {
+/* First half of kalmanStep3DIgnoreAnchor (KalmanFilterTOA.cpp:268-282): ML position -> observation
+ * covariance. Touches the position and the epoch only, not P, so the kernels run it while the covariance
+ * loads are still in flight. Leaves sc.w = 1/R. */
+template <class SC>
+KFPOS_FN void iekf6_weights(const double xhat_p[3], SC &sc, const Params &pr, uint64_t drop, int n_used,
+                            Iekf6Out &o) {
     o.flags = (n_used < 4) ? ST_FEW_RANGES : 0u;
-    /* ML position -> observation covariance (KalmanFilterTOA.cpp:268-282) */
     double pml[3] = {xhat_p[0], xhat_p[1], xhat_p[2]}, e_ml;
     set_weights_ml(sc, pr);
     o.ml_iters = ml_estimate(pml, sc, pr, drop, n_used, e_ml);
@@ -435,7 +452,13 @@ KFPOS_FN void iekf6(const double xhat_p[3], const Cov<6, SYMM> &P, SC &sc,
         e_ml = (n_used == 0) ? -1.0 : ml_sse(xhat_p, sc, pr, drop);
     }
     set_weights_iekf(sc, pr, e_ml);
+}
 
+/* Second half (KalmanFilterTOA.cpp:285-324): the IEKF loop, up to, not including, the covariance
+ * update. xhat_p: predicted position; P: predicted covariance; drop: ignored anchors. */
+template <bool SYMM, class SC>
+KFPOS_FN void iekf6(const double xhat_p[3], const Cov<6, SYMM> &P, SC &sc,
+                    const Params &pr, uint64_t drop, int max_steps, double tol, Iekf6Out &o) {
     double p[3] = {xhat_p[0], xhat_p[1], xhat_p[2]};
     double dp[3] = {0.0, 0.0, 0.0}; /* delta_p = xhat_p - p */
     double qd = 0.0;               /* delta' pinv(P) delta */
@@ -446,12 +469,11 @@ KFPOS_FN void iekf6(const double xhat_p[3], const Cov<6, SYMM> &P, SC &sc,
     for (int iter = 0; iter < max_steps; ++iter) {
         double c = qd, m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0, u0 = 0, u1 = 0, u2 = 0;
         for_anchors<SC>(pr, [&](int a) {
-            if (!used(sc, a, drop)) return;
             const double dx = p[0] - pr.anchors[3 * a], dy = p[1] - pr.anchors[3 * a + 1],
                          dz = p[2] - pr.anchors[3 * a + 2];
             double d, invd;
             kf_sqrt_rsqrt(dx * dx + dy * dy + dz * dz, d, invd);
-            const double w = sc.W(a), y = sc.R(a) - d;
+            const double w = used(sc, a, drop) ? sc.W(a) : 0.0, y = sc.R(a) - d; /* branch-free, see ml_sweep */
             c += y * y * w;
             const double gx = dx * invd, gy = dy * invd, gz = dz * invd;
             const double v = (y - (gx * dp[0] + gy * dp[1] + gz * dp[2])) * w;
@@ -558,53 +580,59 @@ KFPOS_FN uint32_t step_toa6(Tag6<SYMM> &tg, SC &sc, const Params &pr, double dt)
         drop = topn_mask(tg.pos, sc, pr, n_valid);
         n_valid = count_used(sc, pr, drop);
     }
-    predict6(tg.P, dt, pr.accel_noise);
-    const double xhat_p[3] = {tg.pos[0], tg.pos[1], tg.pos[2]};
+    const double xhat_p[3] = {tg.pos[0], tg.pos[1], tg.pos[2]}; /* F x: velocity restarts at 0 */
+    bool predicted = false;
 
     /* kalmanStep3DCanIgnoreAnAnchor (KalmanFilterTOA.cpp:185-238) runs one solve with every range and
      * one per left-out range, then adopts the left-out solve with the largest r_i - |p_(-i) - b_i| if
-     * that is positive and lowers the cost by more than the threshold. Here: phase 0 = all ranges,
-     * phase 1 = the leave-one-out sweep, phase 2 = the adopted set solved once more for its
-     * covariance (same arithmetic, so the same result). Without the heuristic only phase 2 runs.
-     * One call site keeps a single inlined copy of the solver in the kernel. */
-    Iekf6Out o;
+     * that is positive and lowers the cost by more than the threshold. Here one loop walks a virtual
+     * index v: v = -1 solves with every range, v = 0..A-1 leaves range v out (lanes whose range v is
+     * absent sit that trip out), v = A solves the adopted set once more for its covariance (same
+     * arithmetic, hence the same result). Without the heuristic only v = A runs. v is uniform across
+     * the wavefront (anchor coordinates stay scalar loads) and there is ONE call site of the solver,
+     * so the kernel carries a single inlined copy of it. */
+    Iekf6Out o = {};
     int ignored = -1;
     uint64_t chosen = drop;
     const int A = SC::NA > 0 ? SC::NA : pr.n_anchors;
     const bool heuristic = n_valid > 4 && pr.ignore_worst;
-    int phase = heuristic ? 0 : 2, a = -1, i = 0, best_a = -1, best_i = -1;
-    double cost_all = 0.0, max_distance = 0.0, worst_cost = 0.0, ra = 0.0;
-    for (;;) {
-        const uint64_t mask = (phase == 1) ? (drop | (1ull << a)) : (phase == 2 ? chosen : drop);
-        const int n_use = (phase == 1) ? n_valid - 1 : (phase == 2 && ignored >= 0 ? n_valid - 1 : n_valid);
-        iekf6(xhat_p, tg.P, sc, pr, mask, n_use, 10, 1e-3, o);
-        if (phase == 2) break;
-        if (phase == 0) {
+    int i = 0, best_a = -1, best_i = -1;
+    double cost_all = 0.0, max_distance = 0.0, worst_cost = 0.0;
+    for (int v = pr.ignore_worst ? -1 : A; v <= A; ++v) {
+        const bool last = (v == A);
+        double ra = 0.0;
+        bool active = last || (heuristic && v < 0);
+        if (!last && v >= 0 && heuristic) {
+            ra = sc.Rdyn(v);
+            active = !((drop >> v) & 1ull) && ra > 0.0;
+        }
+        if (last && heuristic && max_distance > 0.0 && (cost_all - worst_cost) > pr.cost_threshold) {
+            chosen = drop | (1ull << best_a); /* KalmanFilterTOA.cpp:225-233 */
+            ignored = best_i;
+        }
+        if (!active) continue;
+        const uint64_t mask = last ? chosen : (v < 0 ? drop : (drop | (1ull << v)));
+        const int n_use = last ? (ignored >= 0 ? n_valid - 1 : n_valid) : (v < 0 ? n_valid : n_valid - 1);
+        iekf6_weights(xhat_p, sc, pr, mask, n_use, o);
+        if (!predicted) { /* after the first ML solve: the covariance loads have landed by now */
+            predict6(tg.P, dt, pr.accel_noise);
+            predicted = true;
+        }
+        iekf6(xhat_p, tg.P, sc, pr, mask, 10, 1e-3, o);
+        if (last) break;
+        if (v < 0) {
             cost_all = o.cost;
-            phase = 1;
         } else {
-            const double dx = pr.anchors[3 * a] - o.p[0], dy = pr.anchors[3 * a + 1] - o.p[1],
-                         dz = pr.anchors[3 * a + 2] - o.p[2];
+            const double dx = pr.anchors[3 * v] - o.p[0], dy = pr.anchors[3 * v + 1] - o.p[1],
+                         dz = pr.anchors[3 * v + 2] - o.p[2];
             const double diff = ra - sqrt(dx * dx + dy * dy + dz * dz);
-            if (i == 0 || diff > max_distance) {
+            if (i == 0 || diff > max_distance) { /* KalmanFilterTOA.cpp:209-214 */
                 max_distance = diff;
                 worst_cost = o.cost;
-                best_a = a;
+                best_a = v;
                 best_i = i;
             }
             ++i;
-        }
-        /* next range that is present */
-        for (++a; a < A; ++a) {
-            ra = sc.Rdyn(a);
-            if (!((drop >> a) & 1ull) && ra > 0.0) break;
-        }
-        if (a >= A) {
-            if (max_distance > 0.0 && (cost_all - worst_cost) > pr.cost_threshold) {
-                chosen = drop | (1ull << best_a);
-                ignored = best_i;
-            }
-            phase = 2;
         }
     }
     cov_update6(tg.P, o.mlast);
@@ -747,21 +775,26 @@ struct Iekf9Out {
     uint32_t flags;
 };
 
-/* kalmanStep3D (KalmanFilterTOAIMU.cpp:242-340, with the 3-token repair) up to the covariance update */
+/* kalmanStep3D (KalmanFilterTOAIMU.cpp:242-340, with the 3-token repair), first part (:268-276): ML
+ * position -> observation covariance of the ranging rows. Independent of P. */
 template <class SC>
-KFPOS_FN void iekf9(const double xhat[9], const Cov<9, true> &P, SC &sc, const Params &pr,
-                           bool has_ranging, int n_used, const Imu &imu, int max_steps, double tol,
-                           Iekf9Out &o) {
-    const uint64_t drop = has_ranging ? 0ull : ~0ull;
-    if (!has_ranging) n_used = 0;
+KFPOS_FN void iekf9_weights(const double xhat[9], SC &sc, const Params &pr, bool has_ranging, int n_used,
+                            Iekf9Out &o) {
     o.flags = (has_ranging && n_used < 4) ? ST_FEW_RANGES : 0u;
     o.ml_iters = 0;
     if (has_ranging) {
         double pml[3] = {xhat[0], xhat[1], xhat[2]}, e_ml;
         set_weights_ml(sc, pr);
-        o.ml_iters = ml_estimate(pml, sc, pr, drop, n_used, e_ml); /* no NaN fallback in this filter */
+        o.ml_iters = ml_estimate(pml, sc, pr, 0ull, n_used, e_ml); /* no NaN fallback in this filter */
         set_weights_iekf(sc, pr, e_ml);
     }
+}
+
+/* second part (:296-336): the IEKF loop, up to the covariance update */
+template <class SC>
+KFPOS_FN void iekf9(const double xhat[9], const Cov<9, true> &P, SC &sc, const Params &pr,
+                    bool has_ranging, const Imu &imu, int max_steps, double tol, Iekf9Out &o) {
+    const uint64_t drop = has_ranging ? 0ull : ~0ull;
     double p[3] = {xhat[0], xhat[1], xhat[2]}, acc[3] = {xhat[6], xhat[7], xhat[8]};
     double de[6] = {0, 0, 0, 0, 0, 0}; /* delta on the updated components (position, acceleration) */
     double wl[6] = {0, 0, 0, 0, 0, 0};
@@ -772,21 +805,22 @@ KFPOS_FN void iekf9(const double xhat[9], const Cov<9, true> &P, SC &sc, const P
     o.gain_iters = 0;
     for (int iter = 0; iter < max_steps; ++iter) {
         double c = qd, m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0, u0 = 0, u1 = 0, u2 = 0;
-        for_anchors<SC>(pr, [&](int a) {
-            if (!used(sc, a, drop)) return;
-            const double dx = p[0] - pr.anchors[3 * a], dy = p[1] - pr.anchors[3 * a + 1],
-                         dz = p[2] - pr.anchors[3 * a + 2];
-            double d, invd;
-            kf_sqrt_rsqrt(dx * dx + dy * dy + dz * dz, d, invd);
-            const double w = sc.W(a), y = sc.R(a) - d;
-            c += y * y * w;
-            const double gx = dx * invd, gy = dy * invd, gz = dz * invd;
-            const double v = (y - (gx * de[0] + gy * de[1] + gz * de[2])) * w;
-            u0 += gx * v; u1 += gy * v; u2 += gz * v;
-            const double wx = w * gx, wy = w * gy, wz = w * gz;
-            m0 += wx * gx; m1 += wx * gy; m2 += wx * gz;
-            m3 += wy * gy; m4 += wy * gz; m5 += wz * gz;
-        });
+        if (has_ranging) {
+            for_anchors<SC>(pr, [&](int a) {
+                const double dx = p[0] - pr.anchors[3 * a], dy = p[1] - pr.anchors[3 * a + 1],
+                             dz = p[2] - pr.anchors[3 * a + 2];
+                double d, invd;
+                kf_sqrt_rsqrt(dx * dx + dy * dy + dz * dz, d, invd);
+                const double w = used(sc, a, drop) ? sc.W(a) : 0.0, y = sc.R(a) - d; /* branch-free, see ml_sweep */
+                c += y * y * w;
+                const double gx = dx * invd, gy = dy * invd, gz = dz * invd;
+                const double v = (y - (gx * de[0] + gy * de[1] + gz * de[2])) * w;
+                u0 += gx * v; u1 += gy * v; u2 += gz * v;
+                const double wx = w * gx, wy = w * gy, wz = w * gz;
+                m0 += wx * gx; m1 += wx * gy; m2 += wx * gz;
+                m3 += wy * gy; m4 += wy * gz; m5 += wz * gz;
+            });
+        }
         const double m[6] = {m0, m1, m2, m3, m4, m5}, u[3] = {u0, u1, u2};
         double s[6] = {0, 0, 0, 0, 0, 0};
         if (imu.has) {
@@ -959,7 +993,6 @@ KFPOS_FN uint32_t step_imu9(Tag9 &tg, SC &sc, const Params &pr, double dt,
         tg.P(0, 0) = c[0]; tg.P(0, 1) = c[1]; tg.P(1, 1) = c[3]; /* xy block only, :134-137 */
         return pack_status(ST_ML_INIT, 0, it, -1);
     }
-    predict9(tg.P, dt, pr.jolt);
     const double c = dt * dt / 2;
     double xhat[9];
     KFPOS_UNROLL
@@ -969,7 +1002,9 @@ KFPOS_FN uint32_t step_imu9(Tag9 &tg, SC &sc, const Params &pr, double dt,
         xhat[6 + k] = 0.0;
     }
     Iekf9Out o;
-    iekf9(xhat, tg.P, sc, pr, has_ranging, n_valid, imu, 20, 1e-4, o);
+    iekf9_weights(xhat, sc, pr, has_ranging, n_valid, o); /* needs position + epoch only ... */
+    predict9(tg.P, dt, pr.jolt);                          /* ... so the covariance is first touched here */
+    iekf9(xhat, tg.P, sc, pr, has_ranging, imu, 20, 1e-4, o);
     cov_update9(tg.P, o.mrlast, o.dlast, imu);
     KFPOS_UNROLL
     for (int k = 0; k < 3; ++k) { tg.pos[k] = o.x[k]; tg.vel[k] = o.x[3 + k]; } /* :189-194 */

@@ -96,7 +96,7 @@ __device__ inline Scratch stage_epoch(const KArgs &a, double *lds, int lane, siz
     sc.stride = WAVE;
     for (int k = 0; k < a.A; ++k) {
         const int32_t mm = a.ranges[(size_t)k * a.T + t];
-        sc.r[k * WAVE] = mm > 0 ? (double)mm / 1000 : 0.0; /* Posgenerator.cpp:483-484 */
+        sc.r[k * WAVE] = mm > 0 ? kf_mm_to_m(mm) : 0.0; /* Posgenerator.cpp:483-484 */
         sc.e[k * WAVE] = ld<MREAL>(a.err, (size_t)k * a.T + t);
     }
     return sc;
@@ -105,11 +105,15 @@ __device__ inline Scratch stage_epoch(const KArgs &a, double *lds, int lane, siz
 /* epoch -> registers (anchor count fixed at compile time) */
 template <typename MREAL, int AS>
 __device__ inline void stage_epoch_regs(const KArgs &a, size_t t, RegScratch<AS> &sc) {
+    int32_t mm[AS];
+#pragma unroll
+    for (int k = 0; k < AS; ++k) { /* all loads first: one latency, not AS of them */
+        mm[k] = a.ranges[(size_t)k * a.T + t];
+        sc.e[k] = ld<MREAL>(a.err, (size_t)k * a.T + t);
+    }
 #pragma unroll
     for (int k = 0; k < AS; ++k) {
-        const int32_t mm = a.ranges[(size_t)k * a.T + t];
-        sc.r[k] = mm > 0 ? (double)mm / 1000 : 0.0; /* Posgenerator.cpp:483-484 */
-        sc.e[k] = ld<MREAL>(a.err, (size_t)k * a.T + t);
+        sc.r[k] = mm[k] > 0 ? kf_mm_to_m(mm[k]) : 0.0; /* Posgenerator.cpp:483-484 */
         sc.w[k] = 0.0;
     }
 }
@@ -124,22 +128,22 @@ __global__ __launch_bounds__(WAVE) void k_step_toa6(const KArgs a) {
     const size_t T = a.T;
     const Params pr = make_params(a);
 
+    /* Load order = order of first use: epoch and position feed the ML solve, the covariance is first
+     * touched after it (step_toa6), so its 21-36 loads stay in flight behind ~2-3 k instructions. */
+    RegScratch<(AS > 0 ? AS : 1)> rs;
+    Scratch ls{nullptr, nullptr, nullptr, WAVE};
+    if constexpr (AS > 0) stage_epoch_regs<MREAL, AS>(a, t, rs);
+    else ls = stage_epoch<MREAL>(a, lds, lane, t);
     Tag6<SYMM> tg;
 #pragma unroll
     for (int k = 0; k < 3; ++k) tg.pos[k] = a.pos[k * T + t];
+    const double dt = a.dt ? a.dt[t] : a.dt_shared;
 #pragma unroll
     for (int k = 0; k < Cov<6, SYMM>::SZ; ++k) tg.P.a[k] = ld<REAL>(a.P, k * T + t);
-    const double dt = a.dt ? a.dt[t] : a.dt_shared;
 
     uint32_t s;
-    if constexpr (AS > 0) {
-        RegScratch<AS> sc;
-        stage_epoch_regs<MREAL, AS>(a, t, sc);
-        s = step_toa6<SYMM>(tg, sc, pr, dt);
-    } else {
-        Scratch sc = stage_epoch<MREAL>(a, lds, lane, t);
-        s = step_toa6<SYMM>(tg, sc, pr, dt);
-    }
+    if constexpr (AS > 0) s = step_toa6<SYMM>(tg, rs, pr, dt);
+    else s = step_toa6<SYMM>(tg, ls, pr, dt);
 
     bool fin = true;
 #pragma unroll
@@ -168,6 +172,28 @@ __global__ __launch_bounds__(WAVE) void k_step_imu9(const KArgs a) {
     const size_t T = a.T;
     const Params pr = make_params(a);
     const bool has_ranging = a.mode != MODE_IMU_ONLY;
+
+    /* load order = order of first use (see k_step_toa6): epoch, position, velocity, IMU sample, then the
+     * 45 covariance entries, which are not needed until the ML solve is over */
+    RegScratch<(AS > 0 ? AS : 1)> rs;
+    Scratch ls{nullptr, nullptr, nullptr, WAVE};
+    if constexpr (AS > 0) {
+        if (has_ranging) {
+            stage_epoch_regs<MREAL, AS>(a, t, rs);
+        } else {
+#pragma unroll
+            for (int k = 0; k < AS; ++k) rs.r[k] = rs.e[k] = rs.w[k] = 0.0;
+        }
+    } else {
+        if (has_ranging) ls = stage_epoch<MREAL>(a, lds, lane, t);
+    }
+    Tag9 tg;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        tg.pos[k] = a.pos[k * T + t];
+        tg.vel[k] = a.vel[k * T + t];
+    }
+    const double dt = a.dt ? a.dt[t] : a.dt_shared;
 
     uint32_t fl = a.flags[t];
     Imu imu;
@@ -201,33 +227,13 @@ __global__ __launch_bounds__(WAVE) void k_step_imu9(const KArgs a) {
         cv[7] = ld<MREAL>(a.imu_cov, 4 * T + t);
         cv[8] = ld<MREAL>(a.imu_cov, 5 * T + t);
     }
-    if (imu.has) imu_whitener(cv, imu.ci);
-
-    Tag9 tg;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        tg.pos[k] = a.pos[k * T + t];
-        tg.vel[k] = a.vel[k * T + t];
-    }
 #pragma unroll
     for (int k = 0; k < 45; ++k) tg.P.a[k] = ld<REAL>(a.P, k * T + t);
-    const double dt = a.dt ? a.dt[t] : a.dt_shared;
+    if (imu.has) imu_whitener(cv, imu.ci);
 
     uint32_t s;
-    if constexpr (AS > 0) {
-        RegScratch<AS> sc;
-        if (has_ranging) {
-            stage_epoch_regs<MREAL, AS>(a, t, sc);
-        } else {
-#pragma unroll
-            for (int k = 0; k < AS; ++k) sc.r[k] = sc.e[k] = sc.w[k] = 0.0;
-        }
-        s = step_imu9(tg, sc, pr, dt, has_ranging, imu);
-    } else {
-        Scratch sc{nullptr, nullptr, nullptr, WAVE};
-        if (has_ranging) sc = stage_epoch<MREAL>(a, lds, lane, t);
-        s = step_imu9(tg, sc, pr, dt, has_ranging, imu);
-    }
+    if constexpr (AS > 0) s = step_imu9(tg, rs, pr, dt, has_ranging, imu);
+    else s = step_imu9(tg, ls, pr, dt, has_ranging, imu);
 
     bool fin = true;
 #pragma unroll
