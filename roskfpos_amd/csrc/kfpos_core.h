@@ -15,7 +15,8 @@
  *    diagonal (+ one 3x3 block), so with B = H restricted to those columns E and M = B' R^-1 B
  *        H' S^-1 v = E' (I + M P_ee)^-1 B' R^-1 v          (Woodbury; S = H P H' + R)
  *    replaces the reference's m x m inverse (KalmanFilterTOA.cpp:316-317) by a 3x3 (6-state) or
- *    6x6 (9-state) solve that does not grow with the anchor count.
+ *    6x6 (9-state, solved as 3x3 blocks + Schur complement) system that does not grow with the
+ *    anchor count.
  *  - the state after a gain iteration is x = xhat + P E' w, hence delta = xhat - x = -P E' w and
  *        delta' pinv(P) delta = w' P_ee w = -w . delta_e
  *    for symmetric PSD P of any rank (and for any invertible P), which removes the reference's
@@ -98,6 +99,23 @@ KFPOS_FN void kf_sqrt_rsqrt(double x, double &d, double &invd) {
     invd = kf_rsqrt(x);
     const double s = x * invd;
     d = __builtin_fma(__builtin_fma(-s, s, x) * 0.5, invd, s);
+#else
+    d = sqrt(x);
+    invd = 1.0 / d;
+#endif
+}
+
+/* Variant for the anchor sweeps: d to full precision, invd after ONE Newton step (relative error
+ * ~2e-14: the hardware seed carries ~23 bits). The residual r - d uses d; invd only scales the
+ * Jacobian row (p - b) / d, where 2e-14 moves the result by ~1e-16 m. Saves 3 of 12 instructions. */
+KFPOS_FN void kf_sqrt_rsqrt_sweep(double x, double &d, double &invd) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double y = __builtin_amdgcn_rsq(x);
+    const double e = __builtin_fma(-(0.5 * x) * y, y, 0.5);
+    y = __builtin_fma(y, e, y);
+    const double s = x * y;
+    d = __builtin_fma(__builtin_fma(-s, s, x) * 0.5, y, s);
+    invd = y;
 #else
     d = sqrt(x);
     invd = 1.0 / d;
@@ -266,7 +284,7 @@ KFPOS_FN void ml_sweep(const double p[3], const SC &sc, const Params &pr, uint64
         const double dx = pr.anchors[3 * a] - p[0], dy = pr.anchors[3 * a + 1] - p[1],
                      dz = pr.anchors[3 * a + 2] - p[2];
         double d, invd;
-        kf_sqrt_rsqrt(dx * dx + dy * dy + dz * dz, d, invd);
+        kf_sqrt_rsqrt_sweep(dx * dx + dy * dy + dz * dz, d, invd);
         const double rd = r - d;
         cw_ += rd * rd * w;
         sse_ += on ? rd * rd : 0.0;
@@ -472,7 +490,7 @@ KFPOS_FN void iekf6(const double xhat_p[3], const Cov<6, SYMM> &P, SC &sc,
             const double dx = p[0] - pr.anchors[3 * a], dy = p[1] - pr.anchors[3 * a + 1],
                          dz = p[2] - pr.anchors[3 * a + 2];
             double d, invd;
-            kf_sqrt_rsqrt(dx * dx + dy * dy + dz * dz, d, invd);
+            kf_sqrt_rsqrt_sweep(dx * dx + dy * dy + dz * dz, d, invd);
             const double w = used(sc, a, drop) ? sc.W(a) : 0.0, y = sc.R(a) - d; /* branch-free, see ml_sweep */
             c += y * y * w;
             const double gx = dx * invd, gy = dy * invd, gz = dz * invd;
@@ -663,10 +681,12 @@ struct Imu {
     bool has;      /* hasImuMeasurement */
     double acc[3]; /* linearAcceleration */
     double ci[6];  /* inverse Cholesky factor of the covariance, lower {00,10,20,11,21,22}: Sigma^-1 = Ci' Ci */
+    double wi[6];  /* Sigma^-1 itself, symmetric {00,01,02,11,12,22} */
 };
 
-/* Sigma (row-major 3x3, symmetric positive definite) -> Ci with Sigma^-1 = Ci' Ci */
-KFPOS_FN void imu_whitener(const double s[9], double ci[6]) {
+/* Sigma (row-major 3x3, symmetric positive definite; the lower triangle is read) -> Ci with
+ * Sigma^-1 = Ci' Ci, and Sigma^-1 = Ci' Ci itself */
+KFPOS_FN void imu_whitener(const double s[9], double ci[6], double wi[6]) {
     double c00, c11, c22, i00, i11, i22;
     kf_sqrt_rsqrt(s[0], c00, i00);
     const double c10 = s[3] * i00, c20 = s[6] * i00;
@@ -677,6 +697,12 @@ KFPOS_FN void imu_whitener(const double s[9], double ci[6]) {
     const double i21 = -c21 * i11 * i22;
     const double i20 = -(c20 * i00 + c21 * i10) * i22;
     ci[0] = i00; ci[1] = i10; ci[2] = i20; ci[3] = i11; ci[4] = i21; ci[5] = i22;
+    wi[0] = i00 * i00 + i10 * i10 + i20 * i20;
+    wi[1] = i10 * i11 + i20 * i21;
+    wi[2] = i20 * i22;
+    wi[3] = i11 * i11 + i21 * i21;
+    wi[4] = i21 * i22;
+    wi[5] = i22 * i22;
 }
 
 /* KalmanFilterTOAIMU.cpp:170-180, 392-421 */
@@ -810,7 +836,7 @@ KFPOS_FN void iekf9(const double xhat[9], const Cov<9, true> &P, SC &sc, const P
                 const double dx = p[0] - pr.anchors[3 * a], dy = p[1] - pr.anchors[3 * a + 1],
                              dz = p[2] - pr.anchors[3 * a + 2];
                 double d, invd;
-                kf_sqrt_rsqrt(dx * dx + dy * dy + dz * dz, d, invd);
+                kf_sqrt_rsqrt_sweep(dx * dx + dy * dy + dz * dz, d, invd);
                 const double w = used(sc, a, drop) ? sc.W(a) : 0.0, y = sc.R(a) - d; /* branch-free, see ml_sweep */
                 c += y * y * w;
                 const double gx = dx * invd, gy = dy * invd, gz = dz * invd;
@@ -822,18 +848,23 @@ KFPOS_FN void iekf9(const double xhat[9], const Cov<9, true> &P, SC &sc, const P
             });
         }
         const double m[6] = {m0, m1, m2, m3, m4, m5}, u[3] = {u0, u1, u2};
-        double s[6] = {0, 0, 0, 0, 0, 0};
+        /* IMU rows: y_a = z_a - a, cost += y_a' Sigma^-1 y_a, u_a = D Sigma^-1 (y_a - D delta_a),
+         * M_a = D Sigma^-1 D with D = diag(a) (sic, KalmanFilterTOAIMU.cpp:441-473) */
+        double ua[3] = {0, 0, 0}, ma[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
         if (imu.has) {
-            /* y_a = z_a - a; cost += y_a' Sigma^-1 y_a = |Ci y_a|^2; s_a = Ci (y_a - D delta_a) */
             const double ya[3] = {imu.acc[0] - acc[0], imu.acc[1] - acc[1], imu.acc[2] - acc[2]};
-            const double q0 = imu.ci[0] * ya[0];
-            const double q1 = imu.ci[1] * ya[0] + imu.ci[3] * ya[1];
-            const double q2 = imu.ci[2] * ya[0] + imu.ci[4] * ya[1] + imu.ci[5] * ya[2];
-            c += q0 * q0 + q1 * q1 + q2 * q2;
+            const double wm[3][3] = {{imu.wi[0], imu.wi[1], imu.wi[2]},
+                                     {imu.wi[1], imu.wi[3], imu.wi[4]},
+                                     {imu.wi[2], imu.wi[4], imu.wi[5]}};
             const double va[3] = {ya[0] - acc[0] * de[3], ya[1] - acc[1] * de[4], ya[2] - acc[2] * de[5]};
-            s[3] = imu.ci[0] * va[0];
-            s[4] = imu.ci[1] * va[0] + imu.ci[3] * va[1];
-            s[5] = imu.ci[2] * va[0] + imu.ci[4] * va[1] + imu.ci[5] * va[2];
+            KFPOS_UNROLL
+            for (int i = 0; i < 3; ++i) {
+                const double wy = wm[i][0] * ya[0] + wm[i][1] * ya[1] + wm[i][2] * ya[2];
+                c += ya[i] * wy;
+                ua[i] = acc[i] * (wm[i][0] * va[0] + wm[i][1] * va[1] + wm[i][2] * va[2]);
+                KFPOS_UNROLL
+                for (int j = 0; j < 3; ++j) ma[i][j] = acc[i] * acc[j] * wm[i][j];
+            }
         }
         if (fabs(cost - c) / cost < tol) break; /* KalmanFilterTOAIMU.cpp:316 */
         cost = c;
@@ -841,84 +872,46 @@ KFPOS_FN void iekf9(const double xhat[9], const Cov<9, true> &P, SC &sc, const P
         for (int k = 0; k < 6; ++k) o.mrlast[k] = m[k];
         o.dlast[0] = acc[0]; o.dlast[1] = acc[1]; o.dlast[2] = acc[2];
 
-        Factor9 f;
-        factor9(m, acc, imu, f);
-        /* L_r s_r = u_r (dropped columns give 0) */
-        s[0] = u[0] * f.ilr[0];
-        s[1] = (u[1] - f.lr[1] * s[0]) * f.ilr[1];
-        s[2] = (u[2] - f.lr[2] * s[0] - f.lr[4] * s[1]) * f.ilr[2];
-        /* T = I + L' P_ee L (6x6 symmetric, >= I) */
-        double pl[6][6]; /* P_ee L */
+        /* w = (I + M P_ee)^-1 [u_r; u_a], M = blockdiag(M_r, M_a), by 3x3 blocks:
+         *   [A11 A12; A21 A22] = I + [M_r Ppp, M_r Ppa; M_a Pap, M_a Paa]
+         * A11 and the Schur complement are inverted through their adjugates (both have real
+         * eigenvalues >= 1: products of PSD matrices shifted by I). */
+        const double mr[3][3] = {{m[0], m[1], m[2]}, {m[1], m[3], m[4]}, {m[2], m[4], m[5]}};
+        double a11[9], a12[3][3], a21[3][3], a22[3][3];
         KFPOS_UNROLL
-        for (int i = 0; i < 6; ++i) {
+        for (int i = 0; i < 3; ++i) {
             KFPOS_UNROLL
-            for (int j = 0; j < 6; ++j) {
-                double acc_ = 0.0;
-                KFPOS_UNROLL
-                for (int k = 0; k < 6; ++k) {
-                    /* structural zeros of L fold away at compile time */
-                    const bool nz = (k < 3 && j < 3 && k >= j) || (k >= 3 && j >= 3 && k <= j);
-                    if (nz) acc_ += P(e9(i), e9(k)) * L9(f, k, j);
-                }
-                pl[i][j] = acc_;
+            for (int j = 0; j < 3; ++j) {
+                a11[3 * i + j] = (i == j ? 1.0 : 0.0) + mr[i][0] * P(0, j) + mr[i][1] * P(1, j) + mr[i][2] * P(2, j);
+                a12[i][j] = mr[i][0] * P(0, 6 + j) + mr[i][1] * P(1, 6 + j) + mr[i][2] * P(2, 6 + j);
+                a21[i][j] = ma[i][0] * P(6, j) + ma[i][1] * P(7, j) + ma[i][2] * P(8, j);
+                a22[i][j] = (i == j ? 1.0 : 0.0) + ma[i][0] * P(6, 6 + j) + ma[i][1] * P(7, 6 + j) + ma[i][2] * P(8, 6 + j);
             }
         }
-        Cov<6, true> T;
+        double adj[9];
+        const double id1 = kf_rcp(gen3_adjugate(a11, adj));
+        double xx[3][3], y1[3]; /* X = A11^-1 A12, y1 = A11^-1 u_r */
         KFPOS_UNROLL
-        for (int i = 0; i < 6; ++i) {
+        for (int i = 0; i < 3; ++i) {
+            y1[i] = (adj[3 * i] * u[0] + adj[3 * i + 1] * u[1] + adj[3 * i + 2] * u[2]) * id1;
             KFPOS_UNROLL
-            for (int j = i; j < 6; ++j) {
-                double acc_ = (i == j) ? 1.0 : 0.0;
-                KFPOS_UNROLL
-                for (int k = 0; k < 6; ++k) {
-                    const bool nz = (k < 3 && i < 3 && k >= i) || (k >= 3 && i >= 3 && k <= i);
-                    if (nz) acc_ += L9(f, k, i) * pl[k][j];
-                }
-                T(i, j) = acc_;
-            }
+            for (int j = 0; j < 3; ++j)
+                xx[i][j] = (adj[3 * i] * a12[0][j] + adj[3 * i + 1] * a12[1][j] + adj[3 * i + 2] * a12[2][j]) * id1;
         }
-        /* LDL' of T (no pivoting needed: T is SPD with eigenvalues >= 1), solve T t = s */
-        double dinv[6];
+        double sc9[9], rhs[3]; /* Schur complement A22 - A21 X, rhs u_a - A21 y1 */
         KFPOS_UNROLL
-        for (int j = 0; j < 6; ++j) {
-            double d = T(j, j);
+        for (int i = 0; i < 3; ++i) {
+            rhs[i] = ua[i] - (a21[i][0] * y1[0] + a21[i][1] * y1[1] + a21[i][2] * y1[2]);
             KFPOS_UNROLL
-            for (int k = 0; k < j; ++k) d -= T(k, j) * T(k, j) * dinv[k]; /* T(k,j) holds (L D)(j,k) */
-            dinv[j] = kf_rcp(d);
-            KFPOS_UNROLL
-            for (int i = j + 1; i < 6; ++i) {
-                double v = T(j, i);
-                KFPOS_UNROLL
-                for (int k = 0; k < j; ++k) v -= T(k, i) * T(k, j) * dinv[k];
-                T(j, i) = v; /* = l(i,j) * d_j */
-            }
+            for (int j = 0; j < 3; ++j)
+                sc9[3 * i + j] = a22[i][j] - (a21[i][0] * xx[0][j] + a21[i][1] * xx[1][j] + a21[i][2] * xx[2][j]);
         }
-        double tt[6];
+        const double id2 = kf_rcp(gen3_adjugate(sc9, adj));
         KFPOS_UNROLL
-        for (int i = 0; i < 6; ++i) { /* forward: (L D) z' ... z = L^-1 s */
-            double v = s[i];
-            KFPOS_UNROLL
-            for (int k = 0; k < i; ++k) v -= T(k, i) * dinv[k] * tt[k];
-            tt[i] = v;
-        }
+        for (int i = 0; i < 3; ++i)
+            wl[3 + i] = (adj[3 * i] * rhs[0] + adj[3 * i + 1] * rhs[1] + adj[3 * i + 2] * rhs[2]) * id2;
         KFPOS_UNROLL
-        for (int i = 5; i >= 0; --i) { /* backward: L' t = D^-1 z */
-            double v = tt[i] * dinv[i];
-            KFPOS_UNROLL
-            for (int k = i + 1; k < 6; ++k) v -= T(i, k) * dinv[i] * tt[k];
-            tt[i] = v;
-        }
-        /* w = L t */
-        KFPOS_UNROLL
-        for (int i = 0; i < 6; ++i) {
-            double v = 0.0;
-            KFPOS_UNROLL
-            for (int k = 0; k < 6; ++k) {
-                const bool nz = (i < 3 && k < 3 && i >= k) || (i >= 3 && k >= 3 && i <= k);
-                if (nz) v += L9(f, i, k) * tt[k];
-            }
-            wl[i] = v;
-        }
+        for (int i = 0; i < 3; ++i) wl[i] = y1[i] - (xx[i][0] * wl[3] + xx[i][1] * wl[4] + xx[i][2] * wl[5]);
         /* x_e = xhat_e + P_ee w ; delta_e = -P_ee w ; delta' pinv(P) delta = w . P_ee w */
         qd = 0.0;
         KFPOS_UNROLL

@@ -149,12 +149,12 @@ __global__ __launch_bounds__(WAVE) void k_step_toa6(const KArgs a) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         a.pos[k * T + t] = tg.pos[k];
-        fin = fin && isfinite(tg.pos[k]);
+        fin &= isfinite(tg.pos[k]);
     }
 #pragma unroll
     for (int k = 0; k < Cov<6, SYMM>::SZ; ++k) {
         st<REAL>(a.P, k * T + t, tg.P.a[k]);
-        fin = fin && isfinite(tg.P.a[k]);
+        fin &= isfinite(tg.P.a[k]);
     }
     const bool waiting = !a.use_init_pos && isnan(tg.pos[0]); /* still waiting for its ML initialisation */
     if (!fin && !waiting) s |= ST_NONFINITE;
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(WAVE) void k_step_imu9(const KArgs a) {
     }
 #pragma unroll
     for (int k = 0; k < 45; ++k) tg.P.a[k] = ld<REAL>(a.P, k * T + t);
-    if (imu.has) imu_whitener(cv, imu.ci);
+    if (imu.has) imu_whitener(cv, imu.ci, imu.wi);
 
     uint32_t s;
     if constexpr (AS > 0) s = step_imu9(tg, rs, pr, dt, has_ranging, imu);
@@ -240,12 +240,12 @@ __global__ __launch_bounds__(WAVE) void k_step_imu9(const KArgs a) {
     for (int k = 0; k < 3; ++k) {
         a.pos[k * T + t] = tg.pos[k];
         a.vel[k * T + t] = tg.vel[k];
-        fin = fin && isfinite(tg.pos[k]) && isfinite(tg.vel[k]);
+        fin &= isfinite(tg.pos[k]) & isfinite(tg.vel[k]);
     }
 #pragma unroll
     for (int k = 0; k < 45; ++k) {
         st<REAL>(a.P, k * T + t, tg.P.a[k]);
-        fin = fin && isfinite(tg.P.a[k]);
+        fin &= isfinite(tg.P.a[k]);
     }
     const bool waiting = !a.use_init_pos && isnan(tg.pos[0]);
     if (!fin && !waiting) s |= ST_NONFINITE;

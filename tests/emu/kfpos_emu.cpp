@@ -136,7 +136,7 @@ void kfe_latch_imu(kfe_bank *b, const double *accel, const double *cov) {
         Imu &im = b->imu[t];
         im.has = true;
         for (int k = 0; k < 3; ++k) im.acc[k] = accel[3 * t + k];
-        imu_whitener(cov + 9 * (size_t)t, im.ci);
+        imu_whitener(cov + 9 * (size_t)t, im.ci, im.wi);
         b->flags[t] |= FL_HAS_IMU;
     }
 }
