@@ -41,6 +41,7 @@ namespace {
 using namespace kfpos;
 
 constexpr int WAVE = 64; /* lanes per workgroup = one wavefront */
+#define KFPOS_TRACE_CHUNK 128 /* epochs per multi-epoch launch (their dt values travel in the kernel arguments) */
 
 enum StepMode : int { MODE_TOA = 0, MODE_IMU_ONLY = 1, MODE_FUSED = 2 };
 
@@ -66,6 +67,11 @@ struct KArgs {
     const void *cov;       /* [9][T] real */
     int mode, latch;
     uint32_t *status;      /* [T] or null */
+    /* multi-epoch launches (kfpos_run_trace_dev): epoch s reads its inputs at base + s * stride (elements),
+     * dt_steps[s] is its shared dt. n_steps = 1 is the single-epoch case and uses dt / dt_shared. */
+    int n_steps;
+    long long stride_ranges, stride_err, stride_accel, stride_cov;
+    double dt_steps[KFPOS_TRACE_CHUNK];
 };
 
 template <typename REAL>
@@ -86,36 +92,51 @@ __device__ inline Params make_params(const KArgs &a) {
     return pr;
 }
 
-/* epoch -> per-lane LDS scratch */
+/* Raw epoch of one tag as it sits in HBM: fetched one epoch ahead in multi-epoch launches, so its
+ * latency hides behind the previous epoch's arithmetic. */
+template <typename MREAL, int AS>
+struct RawEpoch {
+    int32_t mm[AS];
+    MREAL e[AS];
+};
+template <typename MREAL, int AS>
+__device__ inline void fetch_epoch(const KArgs &a, size_t t, int s, RawEpoch<MREAL, AS> &raw) {
+    const int32_t *rp = a.ranges + (size_t)s * a.stride_ranges;
+    const MREAL *ep = (const MREAL *)a.err + (size_t)s * a.stride_err;
+#pragma unroll
+    for (int k = 0; k < AS; ++k) { /* all loads first: one latency, not AS of them */
+        raw.mm[k] = rp[(size_t)k * a.T + t];
+        raw.e[k] = ep[(size_t)k * a.T + t];
+    }
+}
+template <typename MREAL, int AS>
+__device__ inline void unpack_epoch(const RawEpoch<MREAL, AS> &raw, RegScratch<AS> &sc) {
+#pragma unroll
+    for (int k = 0; k < AS; ++k) {
+        sc.r[k] = raw.mm[k] > 0 ? kf_mm_to_m(raw.mm[k]) : 0.0; /* Posgenerator.cpp:483-484 */
+        sc.e[k] = (double)raw.e[k];
+        sc.w[k] = 0.0;
+    }
+}
+/* generic anchor count: epoch s -> per-lane LDS scratch */
 template <typename MREAL>
-__device__ inline Scratch stage_epoch(const KArgs &a, double *lds, int lane, size_t t) {
+__device__ inline Scratch stage_epoch_lds(const KArgs &a, double *lds, int lane, size_t t, int s) {
     Scratch sc;
     sc.r = lds + lane;
     sc.e = lds + (size_t)a.A * WAVE + lane;
     sc.w = lds + 2 * (size_t)a.A * WAVE + lane;
     sc.stride = WAVE;
+    const int32_t *rp = a.ranges + (size_t)s * a.stride_ranges;
+    const MREAL *ep = (const MREAL *)a.err + (size_t)s * a.stride_err;
     for (int k = 0; k < a.A; ++k) {
-        const int32_t mm = a.ranges[(size_t)k * a.T + t];
-        sc.r[k * WAVE] = mm > 0 ? kf_mm_to_m(mm) : 0.0; /* Posgenerator.cpp:483-484 */
-        sc.e[k * WAVE] = ld<MREAL>(a.err, (size_t)k * a.T + t);
+        const int32_t mm = rp[(size_t)k * a.T + t];
+        sc.r[k * WAVE] = mm > 0 ? kf_mm_to_m(mm) : 0.0;
+        sc.e[k * WAVE] = (double)ep[(size_t)k * a.T + t];
     }
     return sc;
 }
-
-/* epoch -> registers (anchor count fixed at compile time) */
-template <typename MREAL, int AS>
-__device__ inline void stage_epoch_regs(const KArgs &a, size_t t, RegScratch<AS> &sc) {
-    int32_t mm[AS];
-#pragma unroll
-    for (int k = 0; k < AS; ++k) { /* all loads first: one latency, not AS of them */
-        mm[k] = a.ranges[(size_t)k * a.T + t];
-        sc.e[k] = ld<MREAL>(a.err, (size_t)k * a.T + t);
-    }
-#pragma unroll
-    for (int k = 0; k < AS; ++k) {
-        sc.r[k] = mm[k] > 0 ? kf_mm_to_m(mm[k]) : 0.0; /* Posgenerator.cpp:483-484 */
-        sc.w[k] = 0.0;
-    }
+__device__ inline double epoch_dt(const KArgs &a, size_t t, int s) {
+    return a.n_steps > 1 ? a.dt_steps[s] : (a.dt ? a.dt[t] : a.dt_shared);
 }
 
 /* ------------------------------------------------------------------ 6-state step kernel */
@@ -127,23 +148,37 @@ __global__ __launch_bounds__(WAVE) void k_step_toa6(const KArgs a) {
     if (t >= (size_t)a.T) return;
     const size_t T = a.T;
     const Params pr = make_params(a);
+    constexpr int NA = AS > 0 ? AS : 1;
 
     /* Load order = order of first use: epoch and position feed the ML solve, the covariance is first
      * touched after it (step_toa6), so its 21-36 loads stay in flight behind ~2-3 k instructions. */
-    RegScratch<(AS > 0 ? AS : 1)> rs;
-    Scratch ls{nullptr, nullptr, nullptr, WAVE};
-    if constexpr (AS > 0) stage_epoch_regs<MREAL, AS>(a, t, rs);
-    else ls = stage_epoch<MREAL>(a, lds, lane, t);
+    RawEpoch<MREAL, NA> raw;
+    if constexpr (AS > 0) fetch_epoch<MREAL, AS>(a, t, 0, raw);
     Tag6<SYMM> tg;
 #pragma unroll
     for (int k = 0; k < 3; ++k) tg.pos[k] = a.pos[k * T + t];
-    const double dt = a.dt ? a.dt[t] : a.dt_shared;
 #pragma unroll
     for (int k = 0; k < Cov<6, SYMM>::SZ; ++k) tg.P.a[k] = ld<REAL>(a.P, k * T + t);
 
-    uint32_t s;
-    if constexpr (AS > 0) s = step_toa6<SYMM>(tg, rs, pr, dt);
-    else s = step_toa6<SYMM>(tg, ls, pr, dt);
+    uint32_t s = 0;
+    for (int e = 0; e < a.n_steps; ++e) { /* the state stays in registers from epoch to epoch */
+        const double dt = epoch_dt(a, t, e);
+        if constexpr (AS > 0) {
+            RegScratch<AS> sc;
+            unpack_epoch<MREAL, AS>(raw, sc);
+            if (e + 1 < a.n_steps) fetch_epoch<MREAL, AS>(a, t, e + 1, raw); /* next epoch in flight */
+            s = step_toa6<SYMM>(tg, sc, pr, dt);
+        } else {
+            Scratch sc = stage_epoch_lds<MREAL>(a, lds, lane, t, e);
+            s = step_toa6<SYMM>(tg, sc, pr, dt);
+        }
+        if constexpr (sizeof(REAL) == 4) { /* what n single-epoch launches would have kept in HBM */
+            if (e + 1 < a.n_steps) {
+#pragma unroll
+                for (int k = 0; k < Cov<6, SYMM>::SZ; ++k) tg.P.a[k] = (double)(float)tg.P.a[k];
+            }
+        }
+    }
 
     bool fin = true;
 #pragma unroll
@@ -163,6 +198,20 @@ __global__ __launch_bounds__(WAVE) void k_step_toa6(const KArgs a) {
 }
 
 /* ------------------------------------------------------------------ 9-state step kernel */
+template <typename MREAL>
+struct RawImu {
+    MREAL acc[3], cov[9];
+};
+template <typename MREAL>
+__device__ inline void fetch_imu(const KArgs &a, size_t t, int s, RawImu<MREAL> &raw) {
+    const MREAL *ap = (const MREAL *)a.accel + (size_t)s * a.stride_accel;
+    const MREAL *cp = (const MREAL *)a.cov + (size_t)s * a.stride_cov;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) raw.acc[k] = ap[(size_t)k * a.T + t];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) raw.cov[k] = cp[(size_t)k * a.T + t];
+}
+
 template <typename REAL, typename MREAL, int AS>
 __global__ __launch_bounds__(WAVE) void k_step_imu9(const KArgs a) {
     extern __shared__ double lds[];
@@ -172,20 +221,15 @@ __global__ __launch_bounds__(WAVE) void k_step_imu9(const KArgs a) {
     const size_t T = a.T;
     const Params pr = make_params(a);
     const bool has_ranging = a.mode != MODE_IMU_ONLY;
+    const bool fresh_imu = a.mode != MODE_TOA;
+    constexpr int NA = AS > 0 ? AS : 1;
 
     /* load order = order of first use (see k_step_toa6): epoch, position, velocity, IMU sample, then the
      * 45 covariance entries, which are not needed until the ML solve is over */
-    RegScratch<(AS > 0 ? AS : 1)> rs;
-    Scratch ls{nullptr, nullptr, nullptr, WAVE};
+    RawEpoch<MREAL, NA> raw;
+    RawImu<MREAL> rawi;
     if constexpr (AS > 0) {
-        if (has_ranging) {
-            stage_epoch_regs<MREAL, AS>(a, t, rs);
-        } else {
-#pragma unroll
-            for (int k = 0; k < AS; ++k) rs.r[k] = rs.e[k] = rs.w[k] = 0.0;
-        }
-    } else {
-        if (has_ranging) ls = stage_epoch<MREAL>(a, lds, lane, t);
+        if (has_ranging) fetch_epoch<MREAL, AS>(a, t, 0, raw);
     }
     Tag9 tg;
 #pragma unroll
@@ -193,29 +237,12 @@ __global__ __launch_bounds__(WAVE) void k_step_imu9(const KArgs a) {
         tg.pos[k] = a.pos[k * T + t];
         tg.vel[k] = a.vel[k * T + t];
     }
-    const double dt = a.dt ? a.dt[t] : a.dt_shared;
-
     uint32_t fl = a.flags[t];
     Imu imu;
     imu.has = false;
     double cv[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    if (a.mode != MODE_TOA) { /* fresh sample: newIMUMeasurement latches it (KalmanFilterTOAIMU.cpp:78-89) */
-        imu.has = true;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) imu.acc[k] = ld<MREAL>(a.accel, k * T + t);
-#pragma unroll
-        for (int k = 0; k < 9; ++k) cv[k] = ld<MREAL>(a.cov, k * T + t);
-        if (a.latch) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) st<MREAL>(a.imu_acc, k * T + t, imu.acc[k]);
-            st<MREAL>(a.imu_cov, 0 * T + t, cv[0]);
-            st<MREAL>(a.imu_cov, 1 * T + t, cv[3]);
-            st<MREAL>(a.imu_cov, 2 * T + t, cv[4]);
-            st<MREAL>(a.imu_cov, 3 * T + t, cv[6]);
-            st<MREAL>(a.imu_cov, 4 * T + t, cv[7]);
-            st<MREAL>(a.imu_cov, 5 * T + t, cv[8]);
-            fl |= FL_HAS_IMU;
-        }
+    if (fresh_imu) {
+        fetch_imu<MREAL>(a, t, 0, rawi);
     } else if (fl & FL_HAS_IMU) { /* re-fuse the latched sample (KalmanFilterTOAIMU.cpp:68-72) */
         imu.has = true;
 #pragma unroll
@@ -231,9 +258,51 @@ __global__ __launch_bounds__(WAVE) void k_step_imu9(const KArgs a) {
     for (int k = 0; k < 45; ++k) tg.P.a[k] = ld<REAL>(a.P, k * T + t);
     if (imu.has) imu_whitener(cv, imu.ci, imu.wi);
 
-    uint32_t s;
-    if constexpr (AS > 0) s = step_imu9(tg, rs, pr, dt, has_ranging, imu);
-    else s = step_imu9(tg, ls, pr, dt, has_ranging, imu);
+    uint32_t s = 0;
+    for (int e = 0; e < a.n_steps; ++e) { /* the state stays in registers from epoch to epoch */
+        const double dt = epoch_dt(a, t, e);
+        if (fresh_imu) { /* fresh sample: newIMUMeasurement latches it (KalmanFilterTOAIMU.cpp:78-89) */
+            imu.has = true;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) imu.acc[k] = (double)rawi.acc[k];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) cv[k] = (double)rawi.cov[k];
+            imu_whitener(cv, imu.ci, imu.wi);
+            if (a.latch && e + 1 == a.n_steps) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) st<MREAL>(a.imu_acc, k * T + t, imu.acc[k]);
+                st<MREAL>(a.imu_cov, 0 * T + t, cv[0]);
+                st<MREAL>(a.imu_cov, 1 * T + t, cv[3]);
+                st<MREAL>(a.imu_cov, 2 * T + t, cv[4]);
+                st<MREAL>(a.imu_cov, 3 * T + t, cv[6]);
+                st<MREAL>(a.imu_cov, 4 * T + t, cv[7]);
+                st<MREAL>(a.imu_cov, 5 * T + t, cv[8]);
+                fl |= FL_HAS_IMU;
+            }
+            if (e + 1 < a.n_steps) fetch_imu<MREAL>(a, t, e + 1, rawi);
+        }
+        if constexpr (AS > 0) {
+            RegScratch<AS> sc;
+            if (has_ranging) {
+                unpack_epoch<MREAL, AS>(raw, sc);
+                if (e + 1 < a.n_steps) fetch_epoch<MREAL, AS>(a, t, e + 1, raw);
+            } else {
+#pragma unroll
+                for (int k = 0; k < AS; ++k) sc.r[k] = sc.e[k] = sc.w[k] = 0.0;
+            }
+            s = step_imu9(tg, sc, pr, dt, has_ranging, imu);
+        } else {
+            Scratch sc{nullptr, nullptr, nullptr, WAVE};
+            if (has_ranging) sc = stage_epoch_lds<MREAL>(a, lds, lane, t, e);
+            s = step_imu9(tg, sc, pr, dt, has_ranging, imu);
+        }
+        if constexpr (sizeof(REAL) == 4) { /* what n single-epoch launches would have kept in HBM */
+            if (e + 1 < a.n_steps) {
+#pragma unroll
+                for (int k = 0; k < 45; ++k) tg.P.a[k] = (double)(float)tg.P.a[k];
+            }
+        }
+    }
 
     bool fin = true;
 #pragma unroll
@@ -331,6 +400,7 @@ struct kfpos_handle {
     int msz;      /* sizeof(kfpos_real): bytes per measurement element */
     int A;        /* anchors set */
     bool have_anchors, stepped;
+    int trace_chunk;    /* epochs per launch in kfpos_run_trace_dev (KFPOS_TRACE_CHUNK_STEPS, 1..128) */
     bool force_generic; /* KFPOS_GENERIC_KERNEL=1: always the LDS-staged kernel (A/B measurements, tests) */
     double anchors[KFPOS_MAX_ANCHORS * 3];
     /* device state */
@@ -375,6 +445,8 @@ void fill_args(const kfpos_handle *h, KArgs &a) {
     a.mode = MODE_TOA;
     a.latch = 1;
     a.status = nullptr;
+    a.n_steps = 1;
+    a.stride_ranges = a.stride_err = a.stride_accel = a.stride_cov = 0;
 }
 
 typedef void (*step_kernel_t)(const KArgs);
@@ -519,6 +591,9 @@ int kfpos_create(const kfpos_config *cfg, kfpos_handle **out) {
     {
         const char *g = getenv("KFPOS_GENERIC_KERNEL");
         h->force_generic = g && g[0] == '1';
+        const char *c = getenv("KFPOS_TRACE_CHUNK_STEPS");
+        int n = c ? atoi(c) : KFPOS_TRACE_CHUNK;
+        h->trace_chunk = n < 1 ? 1 : (n > KFPOS_TRACE_CHUNK ? KFPOS_TRACE_CHUNK : n);
     }
     std::memset(h->anchors, 0, sizeof(h->anchors));
     const size_t T = cfg->n_tags, A = cfg->max_anchors, r = h->rsz, m = h->msz;
@@ -671,17 +746,26 @@ int kfpos_run_trace_dev(kfpos_handle *h, int32_t n_steps, const int32_t *range_m
     fill_args(h, a);
     a.status = status;
     a.mode = accel ? MODE_FUSED : MODE_TOA;
-    a.latch = 0;
+    a.stride_ranges = stride_ranges;
+    a.stride_err = stride_err;
+    a.stride_accel = stride_accel;
+    a.stride_cov = stride_cov;
     const size_t r = h->msz;
-    for (int s = 0; s < n_steps; ++s) {
-        a.ranges = range_mm + (size_t)s * stride_ranges;
-        a.err = (const char *)err_est + (size_t)s * stride_err * r;
+    const int chunk = h->trace_chunk;
+    /* Up to `chunk` epochs per launch: the kernel keeps every tag's state in registers across them, so
+     * state traffic and launch boundaries are paid once per chunk instead of once per epoch. */
+    for (int s0 = 0; s0 < n_steps; s0 += chunk) {
+        const int n = n_steps - s0 < chunk ? n_steps - s0 : chunk;
+        a.n_steps = n;
+        a.ranges = range_mm + (size_t)s0 * stride_ranges;
+        a.err = (const char *)err_est + (size_t)s0 * stride_err * r;
         if (accel) {
-            a.accel = (const char *)accel + (size_t)s * stride_accel * r;
-            a.cov = (const char *)cov + (size_t)s * stride_cov * r;
-            a.latch = (s == n_steps - 1) ? 1 : 0; /* leave the last sample latched, as n separate calls would */
+            a.accel = (const char *)accel + (size_t)s0 * stride_accel * r;
+            a.cov = (const char *)cov + (size_t)s0 * stride_cov * r;
+            a.latch = (s0 + n == n_steps) ? 1 : 0; /* leave the last sample latched, as n separate calls would */
         }
-        a.dt_shared = dt_steps[s];
+        for (int k = 0; k < n; ++k) a.dt_steps[k] = dt_steps[s0 + k];
+        a.dt_shared = dt_steps[s0];
         const int rc = launch_step(h, a, (hipStream_t)stream);
         if (rc != KFPOS_OK) return rc;
     }
