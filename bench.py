@@ -2,11 +2,13 @@
 """bench.py -- EKF predict+update throughput of the MI355X batched core on BASELINE.json's metric.
 
 Workload (BASELINE.json configs[2], the configuration the metric is quoted on): 65 536 tags x 8 anchors
-PER GPU, UWB+IMU fused 9-state EKF (kfpos_toa_imu path), fp32 storage / fp64 arithmetic, synthetic
-traces of SURVEY.md 8d. One "step" = one ranging epoch for every tag: predict + full iterated update
-fusing the epoch's accelerometer sample (one kfpos_step_toa_imu_dev launch). All inputs for every step
-are resident in HBM before the timed region. With --gpus N > 1 (weak scaling: every rank owns 65 536
-tags) each step also extrapolates the poses (getPose kernel) and all-gathers them over RCCL.
+PER GPU, UWB+IMU fused 9-state EKF (kfpos_toa_imu path), fp64 arithmetic, synthetic traces of SURVEY.md
+8d. One "step" = one ranging epoch for every tag: predict + full iterated update fusing the epoch's
+accelerometer sample, and the resulting pose written out. All inputs for every step are resident in HBM
+before the timed region. The trace is replayed with kfpos_run_trace_dev: --epochs-per-launch epochs per
+kernel launch (the per-tag state stays in registers between them; 1 = one launch per epoch, which is also
+measured and reported as `per_epoch_launch`). With --gpus N > 1 (weak scaling: every rank owns 65 536 tags)
+the poses at the end of every launch are all-gathered over RCCL, overlapped with the next launch.
 
 Prints ONE JSON line on rank 0 (contract in the task description), with `roofline` for the step kernel
 and `cpu_baseline` = the oracle timed on the host cores over a bounded sample of the same workload.
@@ -92,7 +94,10 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--tags-per-gpu", type=int, default=TAGS_PER_GPU)
+    ap.add_argument("--epochs-per-launch", type=int, default=25,
+                    help="epochs fused into one kernel launch (state resident in registers); 1 = one launch per epoch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-per-epoch", action="store_true", help="skip the extra one-launch-per-epoch measurement")
     args = ap.parse_args()
 
     import torch
@@ -111,24 +116,16 @@ def main():
 
     T = args.tags_per_gpu
     K, W = args.steps, args.warmup
+    E = max(1, min(args.epochs_per_launch, 128))
     lo, hi = shard_range(T * world, world, rank)
     w = Workload(T, ANCHORS, tag0=lo)
     ranges, accel, err, cov, dts = upload_trace(torch, w, W + K, device)
-    bank = capi.KfposBank(capi.MODEL_TOA_IMU, T, w.anchors, storage=STORAGE,
-                          init_pos=w.init_positions(), device=local_rank)
     stream = torch.cuda.current_stream().cuda_stream
-    gather = PoseGather(T, device) if world > 1 else None
+    traj = torch.zeros((W + K, 3, T), dtype=torch.float64, device=device)  # pose after every epoch
 
-    def run_steps(s0, n):
-        if gather is None:
-            bank.run_trace_dev(n, ranges[s0], ANCHORS * T, err, 0, dts[s0:s0 + n], accel=accel[s0],
-                               stride_accel=3 * T, cov=cov, stride_cov=0, stream=stream)
-            return
-        for s in range(s0, s0 + n):
-            bank.step_toa_imu_dev(ranges[s], err, accel[s], cov, dts[s], latch=False, stream=stream)
-            bank.get_pose_dev(0.0, pos=gather.buffer(), stream=stream)
-            gather.gather()
-        gather.wait()
+    def make_bank():
+        return capi.KfposBank(capi.MODEL_TOA_IMU, T, w.anchors, storage=STORAGE,
+                              init_pos=w.init_positions(), device=local_rank)
 
     def fence():
         torch.cuda.synchronize()
@@ -136,29 +133,66 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    run_steps(0, W)
-    fence()
-    bank.timing_begin(stream)
-    t0 = time.perf_counter()
-    run_steps(W, K)
-    kernel_ms = bank.timing_end(stream)  # HIP events on the launch stream around the K step launches
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed, kernel_ms = float(tmax[0]), float(tmax[1])
+    def measure(epochs_per_launch):
+        """W warm-up epochs, then exactly K timed epochs. Every launch covers `epochs_per_launch` epochs
+        (predict + update for every tag in each) and writes the pose after each epoch; with several
+        ranks the poses at the end of every launch are all-gathered over RCCL, overlapped with the next
+        launch. Returns (wall seconds, HIP-event ms around the step launches, number of launches, bank)."""
+        bank = make_bank()
+        gather = PoseGather(T, device) if world > 1 else None
+        launches = 0
 
+        def run(s0, n):
+            nonlocal launches
+            s = s0
+            while s < s0 + n:
+                m = min(epochs_per_launch, s0 + n - s)
+                bank.run_trace_dev(m, ranges[s], ANCHORS * T, err, 0, dts[s:s + m], accel=accel[s],
+                                   stride_accel=3 * T, cov=cov, stride_cov=0, trajectory=traj[s], stream=stream)
+                launches += 1
+                s += m
+                if gather is not None:
+                    gather.buffer().copy_(traj[s - 1], non_blocking=True)
+                    gather.gather()
+            if gather is not None:
+                gather.wait()
+
+        run(0, W)
+        fence()
+        launches = 0
+        bank.timing_begin(stream)
+        t0 = time.perf_counter()
+        run(W, K)
+        kernel_ms = bank.timing_end(stream)  # HIP events on the launch stream around the timed launches
+        fence()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=device)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed, kernel_ms = float(tmax[0]), float(tmax[1])
+        return elapsed, kernel_ms, launches, bank
+
+    elapsed, kernel_ms, launches, bank = measure(E)
     x, P, _ = bank.get_state()
     truth = w.position(w.time_of(W + K - 1))
     track_rms = float(np.sqrt(((x[:, :3] - truth) ** 2).sum(1).mean()))
     finite = bool(np.isfinite(x).all() and np.isfinite(P).all())
+    traj_ok = bool(np.array_equal(traj[W + K - 1].cpu().numpy().T, x[:, :3]))
+    bank.close()
+    per_epoch = None
+    if not args.no_per_epoch and E != 1:
+        e1, k1, l1, b1 = measure(1)
+        b1.close()
+        per_epoch = {"value": T * world * K / e1, "unit": "tag-steps/s", "ms_per_step": e1 * 1e3 / K,
+                     "kernel_us_per_launch": k1 * 1e3 / l1,
+                     "algorithmic_GBps": ALGO_BYTES_PER_TAG_STEP * T / (k1 * 1e-3 / l1) / 1e9}
 
     if rank == 0:
         total_steps = T * world * K
         value = total_steps / elapsed
-        per_launch_s = kernel_ms * 1e-3 / K
-        achieved = ALGO_BYTES_PER_TAG_STEP * T / per_launch_s / 1e9
+        per_launch_s = kernel_ms * 1e-3 / launches
+        units_per_launch = T * K / launches
+        achieved = ALGO_BYTES_PER_TAG_STEP * units_per_launch / per_launch_s / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
@@ -172,25 +206,29 @@ def main():
             "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: 65536 tags x 8 anchors per GPU, UWB+IMU fused 9-state "
-                                   "IEKF (kfpos_toa_imu path), fp32 storage / fp64 arithmetic",
+                                   "IEKF (kfpos_toa_imu path), fp64 arithmetic, f32/int32 measurements, f64 "
+                                   "covariance (KFPOS_STORE_MIXED: a 24-bit covariance misses the 1e-6 m bar)",
                        "tags_per_gpu": T, "anchors": ANCHORS, "total_tags": T * world,
-                       "pose_gather": "rccl all_gather per step" if world > 1 else "none (single GPU)"},
+                       "epochs_per_launch": E, "pose_output": "every epoch ([S][3][T] f64)",
+                       "pose_gather": "rccl all_gather per launch, overlapped" if world > 1 else "none (single GPU)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_step_imu9<float>", "kernel_us_per_launch": per_launch_s * 1e6,
+                         "kernel": "k_step_imu9<double,float,8>", "kernel_us_per_launch": per_launch_s * 1e6,
+                         "units_per_launch": units_per_launch,
                          "algorithmic_bytes_per_tag_step": ALGO_BYTES_PER_TAG_STEP},
-            "state_finite": finite, "rms_vs_truth_m": track_rms,
+            "state_finite": finite, "trajectory_matches_state": traj_ok, "rms_vs_truth_m": track_rms,
         }
+        if per_epoch is not None:
+            out["per_epoch_launch"] = per_epoch
         if world == 1 and not args.no_cpu_baseline:
             threads = min(os.cpu_count() or 1, 16)
-            sample_tags, sample_steps = 8192, 30
+            sample_tags, sample_steps = 16384, 60
             v, secs, rms = cpu_baseline_and_rms(w, w.anchors, sample_tags, sample_steps, threads)
             out["cpu_baseline"] = {"value": v, "unit": "tag-steps/s", "cores": threads, "kind": "port",
                                    "sample": f"first {sample_tags} tags x {sample_steps} steps of the same "
                                              f"workload ({secs:.1f} s of oracle time)"}
             out["rms_pos_err_vs_cpu_ref_m"] = rms
         print(json.dumps(out), flush=True)
-    bank.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

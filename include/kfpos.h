@@ -163,16 +163,22 @@ int kfpos_step_toa_imu_dev(kfpos_handle *h, const int32_t *range_mm, const void 
 int kfpos_get_pose_dev(kfpos_handle *h, double dt_ahead, double *pos, double *cov3x3, double *vel,
                        uint32_t *status, void *stream);
 
-/* Replay a whole trace resident in HBM: n_steps epochs, epoch s reading range_mm + s*step_stride_ranges
- * elements etc. (strides in elements; err_est/cov strides may be 0 to reuse one array). Equivalent to
- * n_steps calls of kfpos_step_toa_dev / kfpos_step_toa_imu_dev (accel != NULL) with dt_steps[s] shared by
- * all tags (host array). Launches are enqueued back to back on `stream`. */
+/* Replay a whole trace resident in HBM: n_steps epochs, epoch s reading range_mm + s*stride_ranges
+ * elements etc. (strides in elements; err_est / cov strides may be 0 to reuse one array). Equivalent, bit
+ * for bit, to n_steps calls of kfpos_step_toa_dev / kfpos_step_toa_imu_dev (accel != NULL) with
+ * dt_steps[s] (host array) shared by all tags -- but up to 128 epochs run inside ONE launch with every
+ * tag's state resident in registers, so state traffic and launch boundaries are paid once per launch
+ * instead of once per epoch (KFPOS_TRACE_CHUNK_STEPS=n in the environment caps the epochs per launch;
+ * 1 = one launch per epoch).
+ *   trajectory  [n_steps][3][n_tags] double or NULL: the position after every epoch, i.e. what a caller
+ *               polling getPose at timeLag 0 after each epoch would have read (Posgenerator.cpp:541-548)
+ *   status      [n_tags] status words of the LAST epoch, or NULL */
 int kfpos_run_trace_dev(kfpos_handle *h, int32_t n_steps,
                         const int32_t *range_mm, int64_t stride_ranges,
                         const void *err_est, int64_t stride_err,
                         const void *accel, int64_t stride_accel,
                         const void *cov, int64_t stride_cov,
-                        const double *dt_steps, uint32_t *status, void *stream);
+                        const double *dt_steps, double *trajectory, uint32_t *status, void *stream);
 
 /* ---- diagnostics ---- */
 const char *kfpos_last_error(void);  /* thread-local text of the last KFPOS_ERR_HIP */

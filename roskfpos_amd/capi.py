@@ -78,7 +78,7 @@ def load():
     L.kfpos_step_toa_imu_dev.argtypes = [vp, vp, vp, vp, vp, i32, vp, f64, vp, vp]
     L.kfpos_get_pose_dev.argtypes = [vp, f64, vp, vp, vp, vp, vp]
     L.kfpos_run_trace_dev.argtypes = [vp, i32, vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, vp, C.c_int64,
-                                      vp, vp, vp]
+                                      vp, vp, vp, vp]
     L.kfpos_timing_begin.argtypes = [vp, vp]
     L.kfpos_timing_end.argtypes = [vp, vp, C.POINTER(C.c_float)]
     L.kfpos_last_error.restype = C.c_char_p
@@ -226,12 +226,12 @@ class KfposBank:
                                               _ptr(status), _ptr(stream)))
 
     def run_trace_dev(self, n_steps, range_mm, stride_ranges, err_est, stride_err, dt_steps, accel=None,
-                      stride_accel=0, cov=None, stride_cov=0, status=None, stream=None):
+                      stride_accel=0, cov=None, stride_cov=0, trajectory=None, status=None, stream=None):
         d = np.ascontiguousarray(dt_steps, dtype=np.float64)
         assert d.size >= n_steps
         self._chk(self.lib.kfpos_run_trace_dev(self._h, n_steps, _ptr(range_mm), stride_ranges, _ptr(err_est),
                                                stride_err, _ptr(accel), stride_accel, _ptr(cov), stride_cov,
-                                               d.ctypes.data, _ptr(status), _ptr(stream)))
+                                               d.ctypes.data, _ptr(trajectory), _ptr(status), _ptr(stream)))
 
     def timing_begin(self, stream=None):
         self._chk(self.lib.kfpos_timing_begin(self._h, _ptr(stream)))

@@ -71,6 +71,7 @@ struct KArgs {
      * dt_steps[s] is its shared dt. n_steps = 1 is the single-epoch case and uses dt / dt_shared. */
     int n_steps;
     long long stride_ranges, stride_err, stride_accel, stride_cov;
+    double *traj;          /* [n_steps][3][T] positions after each epoch, or null */
     double dt_steps[KFPOS_TRACE_CHUNK];
 };
 
@@ -171,6 +172,10 @@ __global__ __launch_bounds__(WAVE) void k_step_toa6(const KArgs a) {
         } else {
             Scratch sc = stage_epoch_lds<MREAL>(a, lds, lane, t, e);
             s = step_toa6<SYMM>(tg, sc, pr, dt);
+        }
+        if (a.traj) { /* the pose a per-epoch caller would have read back (getPose at timeLag 0) */
+#pragma unroll
+            for (int k = 0; k < 3; ++k) a.traj[((size_t)e * 3 + k) * T + t] = tg.pos[k];
         }
         if constexpr (sizeof(REAL) == 4) { /* what n single-epoch launches would have kept in HBM */
             if (e + 1 < a.n_steps) {
@@ -295,6 +300,10 @@ __global__ __launch_bounds__(WAVE) void k_step_imu9(const KArgs a) {
             Scratch sc{nullptr, nullptr, nullptr, WAVE};
             if (has_ranging) sc = stage_epoch_lds<MREAL>(a, lds, lane, t, e);
             s = step_imu9(tg, sc, pr, dt, has_ranging, imu);
+        }
+        if (a.traj) { /* the pose a per-epoch caller would have read back (getPose at timeLag 0) */
+#pragma unroll
+            for (int k = 0; k < 3; ++k) a.traj[((size_t)e * 3 + k) * T + t] = tg.pos[k];
         }
         if constexpr (sizeof(REAL) == 4) { /* what n single-epoch launches would have kept in HBM */
             if (e + 1 < a.n_steps) {
@@ -447,6 +456,7 @@ void fill_args(const kfpos_handle *h, KArgs &a) {
     a.status = nullptr;
     a.n_steps = 1;
     a.stride_ranges = a.stride_err = a.stride_accel = a.stride_cov = 0;
+    a.traj = nullptr;
 }
 
 typedef void (*step_kernel_t)(const KArgs);
@@ -737,8 +747,8 @@ int kfpos_step_toa_imu_dev(kfpos_handle *h, const int32_t *range_mm, const void 
 
 int kfpos_run_trace_dev(kfpos_handle *h, int32_t n_steps, const int32_t *range_mm, int64_t stride_ranges,
                         const void *err_est, int64_t stride_err, const void *accel, int64_t stride_accel,
-                        const void *cov, int64_t stride_cov, const double *dt_steps, uint32_t *status,
-                        void *stream) {
+                        const void *cov, int64_t stride_cov, const double *dt_steps, double *trajectory,
+                        uint32_t *status, void *stream) {
     if (!h || n_steps < 0 || !range_mm || !err_est || !dt_steps) return KFPOS_ERR_ARG;
     if (accel && (!cov || h->cfg.model != KFPOS_MODEL_TOA_IMU)) return KFPOS_ERR_MODEL;
     if (!h->have_anchors) return KFPOS_ERR_STATE;
@@ -766,6 +776,7 @@ int kfpos_run_trace_dev(kfpos_handle *h, int32_t n_steps, const int32_t *range_m
         }
         for (int k = 0; k < n; ++k) a.dt_steps[k] = dt_steps[s0 + k];
         a.dt_shared = dt_steps[s0];
+        a.traj = trajectory ? trajectory + (size_t)s0 * 3 * h->cfg.n_tags : nullptr;
         const int rc = launch_step(h, a, (hipStream_t)stream);
         if (rc != KFPOS_OK) return rc;
     }

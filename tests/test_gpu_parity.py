@@ -187,7 +187,9 @@ def test_device_api_and_trace_replay_equal_host_api(model, storage):
     dev = capi.KfposBank(model, T, w.anchors, storage=storage, init_pos=w.init_positions())
     rep = capi.KfposBank(model, T, w.anchors, storage=storage, init_pos=w.init_positions())
     st_t = torch.zeros(T, dtype=torch.int32, device="cuda:0")
+    traj_t = torch.zeros(S, 3, T, dtype=torch.float64, device="cuda:0")
     stream = torch.cuda.current_stream().cuda_stream
+    pos_hist = []
     for s in range(S):
         if model == 1:
             sh = host.step_toa_imu(r[s], w.err_est(real), a[s].astype(real), w.accel_cov(real), dt[s])
@@ -195,14 +197,18 @@ def test_device_api_and_trace_replay_equal_host_api(model, storage):
         else:
             sh = host.step_toa(r[s], w.err_est(real), dt[s])
             dev.step_toa_dev(rt[s], et, dt[s], status=st_t, stream=stream)
+        pos_hist.append(host.get_pose(0.0)[0])
     torch.cuda.synchronize()
     assert np.array_equal(sh, st_t.cpu().numpy().astype(np.uint32))
     if model == 1:
         rep.run_trace_dev(S, rt, A * T, et, 0, dt, accel=at, stride_accel=3 * T, cov=ct, stride_cov=0,
-                          stream=stream)
+                          trajectory=traj_t, status=st_t, stream=stream)
     else:
-        rep.run_trace_dev(S, rt, A * T, et, 0, dt, stream=stream)
+        rep.run_trace_dev(S, rt, A * T, et, 0, dt, trajectory=traj_t, status=st_t, stream=stream)
     torch.cuda.synchronize()
+    # one multi-epoch launch == S single-epoch launches: last status, every intermediate pose, final state
+    assert np.array_equal(sh, st_t.cpu().numpy().astype(np.uint32))
+    assert np.array_equal(traj_t.cpu().numpy().transpose(0, 2, 1), np.stack(pos_hist))
     xh, Ph, _ = host.get_state()
     for other in (dev, rep):
         xo, Po, _ = other.get_state()
