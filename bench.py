@@ -109,10 +109,16 @@ def main():
             raise SystemExit("launch with python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
+    # one rank per GPU; KFPOS_BENCH_BACKEND=gloo lets several ranks share one card to rehearse the N>1 code path
+    backend = os.environ.get("KFPOS_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device(device))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(device))
+        else:
+            dist.init_process_group(backend)
 
     T = args.tags_per_gpu
     K, W = args.steps, args.warmup

@@ -43,7 +43,9 @@ class PoseGather:
         self.flat = [torch.zeros(self.world * 3, t_local, dtype=dtype, device=device) for _ in range(2)]
         self.full = [f.view(self.world, 3, t_local) for f in self.flat]
         self.cuda = torch.device(device).type == "cuda"
-        self.overlap = overlap and self.cuda
+        # gloo has no device collectives: stage through the host (rehearsals of the N>1 path on one card)
+        self.host_staged = self.cuda and dist.is_initialized() and dist.get_backend() == "gloo"
+        self.overlap = overlap and self.cuda and not self.host_staged
         if self.cuda:
             self.comm = torch.cuda.Stream(device=device) if self.overlap else None
             self.ready = [torch.cuda.Event() for _ in range(2)]
@@ -73,6 +75,11 @@ class PoseGather:
                 self.dist.all_gather_into_tensor(self.flat[b], self.local[b])
                 self.done[b].record(self.comm)
             self.used[b] = True
+        elif self.host_staged:
+            src = self.local[b].cpu()
+            dst = self.torch.zeros(self.flat[b].shape, dtype=src.dtype)
+            self.dist.all_gather_into_tensor(dst, src)
+            self.flat[b].copy_(dst)
         else:
             self.dist.all_gather_into_tensor(self.flat[b], self.local[b])
         return self.full[b]

@@ -29,14 +29,17 @@ _M2 = np.uint64(0x94D049BB133111EB)
 
 
 def anchors_xyz(n_anchors: int) -> np.ndarray:
-    """Anchor table (A, 3) float64: 8 room corners, then 8 interior anchors."""
-    if not 1 <= n_anchors <= 16:
-        raise ValueError("synthetic anchor layout is defined for 1..16 anchors")
-    out = np.zeros((16, 3))
+    """Anchor table (A, 3) float64: 8 room corners, 8 interior anchors, then -- only for
+    tests of large anchor counts, up to MAX_NUM_ANCS = 64 -- a second ring."""
+    if not 1 <= n_anchors <= 64:
+        raise ValueError("synthetic anchor layout is defined for 1..64 anchors")
+    out = np.zeros((64, 3))
     for i in range(8):
         out[i] = (10.0 * (i & 1), 10.0 * ((i >> 1) & 1), 0.3 + 2.7 * ((i >> 2) & 1))
     for i in range(8, 16):
         out[i] = (5.0 + 3.0 * np.cos(float(i)), 5.0 + 3.0 * np.sin(float(i)), 1.5 + 0.1 * i)
+    for i in range(16, 64):
+        out[i] = (5.0 + 4.5 * np.cos(0.7 * i), 5.0 + 4.5 * np.sin(0.7 * i), 0.4 + 0.04 * i)
     return out[:n_anchors].copy()
 
 

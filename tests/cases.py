@@ -60,6 +60,10 @@ CASES = [
     Case("imu9_A8_mlinit", MODEL_TOA_IMU, 8, fixed=False),
     Case("imu9_A8_latched", MODEL_TOA_IMU, 8, imu_every=3, cov_full=True),
     Case("imu9_A8_separate", MODEL_TOA_IMU, 8, separate_imu=True),
+    # anchor counts without a specialised kernel: the generic LDS-staged path (64 = MAX_NUM_ANCS needs 96 KB of LDS)
+    Case("toa6_A5_generic", MODEL_TOA, 5, T=24, S=40),
+    Case("imu9_A12_generic", MODEL_TOA_IMU, 12, T=24, S=40),
+    Case("toa6_A64_generic", MODEL_TOA, 64, T=24, S=30, ignore_worst=True, outlier=True),
 ]
 CASE_BY_NAME = {c.name: c for c in CASES}
 
