@@ -56,6 +56,7 @@ extern "C" {
 #define KFPOS_ST_ML_INIT        0x08u /* this epoch was consumed by the ML initialisation (KalmanFilterTOA.cpp:90-108) */
 #define KFPOS_ST_NOT_STARTED    0x10u /* getPose() == false: no measurement yet (KalmanFilterTOA.cpp:442-447) */
 #define KFPOS_ST_NONFINITE      0x20u /* state not finite after the call */
+#define KFPOS_ST_SKIPPED        0x40u /* dt < 0 was passed for this tag: no estimator call, filter untouched */
 #define KFPOS_ST_GAIN_ITERS(s)  (((s) >> 8) & 0xffu)  /* IEKF gain iterations (KalmanFilterTOA.cpp:293-324) */
 #define KFPOS_ST_ML_ITERS(s)    (((s) >> 16) & 0xffu) /* ML Gauss-Newton iterations, saturating (MLLocation.cpp:168-225) */
 #define KFPOS_ST_IGNORED(s)     ((int)(((s) >> 24) & 0xffu) - 1) /* index among this epoch's >0 ranges of the anchor the
@@ -106,7 +107,9 @@ int kfpos_real_size(const kfpos_handle *h);
  *             (Posgenerator.cpp:213); <= 0 = no range from that anchor this epoch (:483)
  *   err_est   n_tags x max_anchors, kfpos_real, m^2, must be > 0 where a range is present (:485)
  *   dt        seconds since the previous estimate of each tag (the reference's wall-clock timeLag;
- *             0.1 on a filter's first call, KalmanFilterTOA.cpp:81); dt_len = 1 (shared) or n_tags
+ *             0.1 on a filter's first call, KalmanFilterTOA.cpp:81); dt_len = 1 (shared) or n_tags.
+ *             With dt_len = n_tags a NEGATIVE dt[t] means "tag t has no epoch in this call": its filter is
+ *             left untouched (tags report asynchronously; kfpos_ingest.h batches whoever flushed)
  *   status    n_tags words or NULL
  * A 9-state handle fuses the latched IMU sample again, as the reference does (KalmanFilterTOAIMU.cpp:68-72). */
 int kfpos_step_toa(kfpos_handle *h, const int32_t *range_mm, const void *err_est,
@@ -134,6 +137,10 @@ int kfpos_step_toa_imu(kfpos_handle *h, const int32_t *range_mm, const void *err
  * yet reports KFPOS_ST_NOT_STARTED and NaN (getPose() == false). */
 int kfpos_get_pose(kfpos_handle *h, double dt_ahead, double *pos, double *cov3x3, double *vel,
                    uint32_t *status);
+/* Same with one extrapolation time per tag (dt_ahead: n_tags doubles): tags report asynchronously, so
+ * "now minus the time of my last estimate" differs from tag to tag (KalmanFilterTOA.cpp:451-452). */
+int kfpos_get_pose_each(kfpos_handle *h, const double *dt_ahead, double *pos, double *cov3x3, double *vel,
+                        uint32_t *status);
 
 /* Raw filter members for tests and checkpoint/restore: x n_tags x n ([p, v(, a = 0)]),
  * P n_tags x n x n row-major, double. n = kfpos_state_dim(). flags: n_tags words (bit 0 started,

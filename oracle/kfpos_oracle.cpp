@@ -8,11 +8,17 @@
  * operation order, with every Armadillo call replaced by the mathematical
  * contract Armadillo documents for it:
  *   inv(A)            LU with partial pivoting; failure ("std::runtime_error")
- *                     on an exactly zero pivot or non-finite input
- *   pinv(A)           SVD, singular values below max(m,n)*s_max*eps dropped
+ *                     on an exactly zero pivot; NaN/inf input propagates (LAPACK
+ *                     getrf/getri do not reject it)
+ *   pinv(A)           SVD, singular values below max(m,n)*s_max*eps dropped;
+ *                     failure on non-finite input (the SVD does not converge)
  *   solve(A,b,equilibrate)
  *                     row/column equilibration, LU, one step of iterative
- *                     refinement; rcond < eps falls back to pinv(A)*b
+ *                     refinement; rcond < eps falls back to pinv(A)*b; NaN/inf
+ *                     input gives a NaN solution, not a failure -- the reference
+ *                     itself tests the ML position for NaN and falls back
+ *                     (KalmanFilterTOA.cpp:270-272), which only makes sense if
+ *                     solve() hands NaN through
  *   std::max(a,b)     (a < b) ? b : a   -- matters for NaN
  * Armadillo itself is an unpinned third-party dependency of the reference
  * (CMakeLists.txt:29, find_package(Armadillo REQUIRED), no version).
@@ -127,7 +133,10 @@ bool inv_lu(const Mat &A, Mat &out) {
     const int n = A.r;
     out = Mat(n, n);
     if (n == 0) return true;
-    if (!all_finite(A)) return false;
+    if (!all_finite(A)) { /* NaN in, NaN out */
+        for (double &v : out.a) v = NAN;
+        return true;
+    }
     Mat LU = A;
     std::vector<int> piv;
     if (!lu_factor(LU, piv)) return false;
@@ -212,9 +221,12 @@ bool solve_equil(const Mat &A, const std::vector<double> &b, std::vector<double>
     const int n = A.r;
     x.assign(n, 0.0);
     if (n == 0) return true;
-    if (!all_finite(A)) return false;
-    for (double v : b)
-        if (!std::isfinite(v)) return false;
+    bool finite = all_finite(A);
+    for (double v : b) finite = finite && std::isfinite(v);
+    if (!finite) { /* NaN in, NaN out */
+        x.assign(n, NAN);
+        return true;
+    }
     /* dgeequ / dlaqge */
     const double smlnum = std::numeric_limits<double>::min() / EPS, bignum = 1.0 / smlnum;
     std::vector<double> R(n, 1.0), C(n, 1.0);
@@ -793,6 +805,10 @@ void kfo_step_toa(kfo_filter_bank *o, const int32_t *range_mm, const double *err
             Tag &tg = o->tags[t];
             std::vector<Meas> m = gather(o, range_mm + (size_t)t * o->A, err_est + (size_t)t * o->A);
             const double lag = dt[dt_len > 1 ? t : 0];
+            if (dt_len > 1 && lag < 0) { /* no epoch for this tag: the reference makes no call at all */
+                if (status) status[t] = KFO_ST_SKIPPED;
+                continue;
+            }
             unsigned st = (o->pr.n == 6) ? toa6_estimate(o->pr, tg, m, lag)
                                          : imu9_estimate(o->pr, tg, true, m, tg.hasImu, lag);
             const bool uninit = !o->pr.useFixedInit && std::isnan(tg.pos[0]); /* still waiting for ML init */
@@ -808,6 +824,10 @@ void kfo_step_imu(kfo_filter_bank *o, const double *accel, const double *cov, co
         for (int t = lo; t < hi; ++t) {
             Tag &tg = o->tags[t];
             unsigned st = 0;
+            if (dt_len > 1 && dt[t] < 0) {
+                if (status) status[t] = KFO_ST_SKIPPED;
+                continue;
+            }
             if (o->pr.n == 9) { /* KalmanFilterTOA::newIMUMeasurement is a no-op (KalmanFilterTOA.cpp:64) */
                 std::memcpy(tg.imuAcc, accel + 3 * (size_t)t, 3 * sizeof(double));
                 std::memcpy(tg.imuCov, cov + 9 * (size_t)t, 9 * sizeof(double));

@@ -35,6 +35,7 @@ typedef struct kfo_filter_bank kfo_filter_bank;
 #define KFO_ST_ML_INIT        0x08u /* this call was the ML initialisation (KalmanFilterTOA.cpp:90-108) */
 #define KFO_ST_NOT_STARTED    0x10u /* getPose before the first measurement (KalmanFilterTOA.cpp:442-447) */
 #define KFO_ST_NONFINITE      0x20u /* state is not finite after the call */
+#define KFO_ST_SKIPPED        0x40u /* dt < 0: this tag's filter was not called */
 /* bits 8..15: IEKF gain iterations; 16..23: ML Gauss-Newton iterations (sat. 255);
  * 24..31: 1 + index (into the >0 ranges of the epoch) of the anchor dropped by
  * the leave-one-out heuristic, 0 if none. */

@@ -27,7 +27,7 @@ def arma_inv(A):
     if A.size == 0:
         return A.copy()
     if not np.all(np.isfinite(A)):
-        raise LinAlgThrow("inv")
+        return np.full_like(A, np.nan)  # NaN in, NaN out (LAPACK getrf/getri do not reject it)
     try:
         return np.linalg.inv(A)
     except np.linalg.LinAlgError as e:
@@ -47,7 +47,7 @@ def arma_pinv(A):
 
 def arma_solve_equilibrate(A, b):
     if not (np.all(np.isfinite(A)) and np.all(np.isfinite(b))):
-        raise LinAlgThrow("solve")
+        return np.full_like(b, np.nan)  # the reference tests the result for NaN (KalmanFilterTOA.cpp:270)
     if np.linalg.cond(A, 1) * EPS > 1.0:
         return arma_pinv(A) @ b
     try:

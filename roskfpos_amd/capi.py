@@ -19,11 +19,13 @@ MODEL_TOA, MODEL_TOA_IMU = 0, 1
 STORE_F64, STORE_F32, STORE_MIXED = 0, 1, 2
 MAX_ANCHORS = 64
 ST_UPDATE_SKIPPED, ST_ML_FALLBACK, ST_FEW_RANGES, ST_ML_INIT, ST_NOT_STARTED, ST_NONFINITE = 1, 2, 4, 8, 16, 32
+ST_SKIPPED = 64
 
 # every symbol include/kfpos.h declares
 EXPORTS = [
     "kfpos_create", "kfpos_destroy", "kfpos_init", "kfpos_set_anchors", "kfpos_set_init_positions",
     "kfpos_real_size", "kfpos_step_toa", "kfpos_step_imu", "kfpos_step_toa_imu", "kfpos_get_pose",
+    "kfpos_get_pose_each",
     "kfpos_state_dim", "kfpos_get_state", "kfpos_set_state", "kfpos_step_toa_dev", "kfpos_step_imu_dev",
     "kfpos_step_toa_imu_dev", "kfpos_get_pose_dev", "kfpos_run_trace_dev", "kfpos_last_error",
     "kfpos_strerror", "kfpos_version", "kfpos_timing_begin", "kfpos_timing_end",
@@ -71,6 +73,7 @@ def load():
     L.kfpos_step_imu.argtypes = [vp, vp, vp, vp, i32, vp]
     L.kfpos_step_toa_imu.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp]
     L.kfpos_get_pose.argtypes = [vp, f64, vp, vp, vp, vp]
+    L.kfpos_get_pose_each.argtypes = [vp, vp, vp, vp, vp, vp]
     L.kfpos_get_state.argtypes = [vp, vp, vp, vp]
     L.kfpos_set_state.argtypes = [vp, vp, vp, vp]
     L.kfpos_step_toa_dev.argtypes = [vp, vp, vp, vp, f64, vp, vp]
@@ -191,6 +194,15 @@ class KfposBank:
         st = np.zeros(self.T, dtype=np.uint32)
         self._chk(self.lib.kfpos_get_pose(self._h, dt_ahead, pos.ctypes.data, cov.ctypes.data,
                                           vel.ctypes.data, st.ctypes.data))
+        return pos, cov.reshape(self.T, 3, 3), vel, st
+
+    def get_pose_each(self, dt_ahead):
+        d = np.ascontiguousarray(dt_ahead, dtype=np.float64)
+        assert d.shape == (self.T,)
+        pos, cov, vel = np.zeros((self.T, 3)), np.zeros((self.T, 9)), np.zeros((self.T, 3))
+        st = np.zeros(self.T, dtype=np.uint32)
+        self._chk(self.lib.kfpos_get_pose_each(self._h, d.ctypes.data, pos.ctypes.data, cov.ctypes.data,
+                                               vel.ctypes.data, st.ctypes.data))
         return pos, cov.reshape(self.T, 3, 3), vel, st
 
     def get_state(self):

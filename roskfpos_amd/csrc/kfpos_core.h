@@ -56,6 +56,7 @@ enum : uint32_t {
     ST_ML_INIT        = 0x08u, /* this call was the ML initialisation (KalmanFilterTOA.cpp:90-108) */
     ST_NOT_STARTED    = 0x10u, /* getPose before any measurement (KalmanFilterTOA.cpp:442-447) */
     ST_NONFINITE      = 0x20u, /* state not finite after the call */
+    ST_SKIPPED        = 0x40u, /* dt < 0: no epoch for this tag in this call, filter untouched */
 };
 /* persisted per-tag flag bits */
 enum : uint32_t { FL_STARTED = 1u, FL_HAS_IMU = 2u };
@@ -372,6 +373,18 @@ KFPOS_FN void ml_covariance(const double p[3], const SC &sc, const Params &pr, d
     for (int k = 0; k < 6; ++k) cov[k] = c[k] * idet;
 }
 
+/* MLLocation::estimatePosition ends with inv(diagmat(max(e_i, e_ML))) and inv(J' W J) (MLLocation.cpp:248-252).
+ * The first one throws std::runtime_error when an entry is exactly 0 -- which is what an errorEstimation of 0
+ * leads to: the 1/e weights make the ML position NaN, e_ML is NaN, std::max(e_i, NaN) = e_i = 0. The
+ * 6-state filter swallows the exception and skips the update (KalmanFilterTOA.cpp:151-153). */
+template <class SC>
+KFPOS_FN bool ml_covariance_throws(const SC &sc, const Params &pr, uint64_t drop, int n_used, double sse) {
+    if (n_used < 4) return false; /* estimatePosition returned before getting there */
+    bool bad = false;
+    for_anchors<SC>(pr, [&](int a) { bad = bad || (used(sc, a, drop) && stdmax(sc.E(a), sse) == 0.0); });
+    return bad;
+}
+
 template <class SC>
 KFPOS_FN void set_weights_ml(SC &sc, const Params &pr) {
     for_anchors<SC>(pr, [&](int a) { sc.setW(a, kf_rcp(sc.E(a))); });
@@ -465,6 +478,7 @@ KFPOS_FN void iekf6_weights(const double xhat_p[3], SC &sc, const Params &pr, ui
     double pml[3] = {xhat_p[0], xhat_p[1], xhat_p[2]}, e_ml;
     set_weights_ml(sc, pr);
     o.ml_iters = ml_estimate(pml, sc, pr, drop, n_used, e_ml);
+    if (ml_covariance_throws(sc, pr, drop, n_used, e_ml)) o.flags |= ST_UPDATE_SKIPPED;
     if (isnan(pml[0]) || isnan(pml[1]) || isnan(pml[2])) {
         o.flags |= ST_ML_FALLBACK;
         e_ml = (n_used == 0) ? -1.0 : ml_sse(xhat_p, sc, pr, drop);
@@ -581,6 +595,7 @@ KFPOS_FN uint32_t step_toa6(Tag6<SYMM> &tg, SC &sc, const Params &pr, double dt)
         double p[3] = {1.0, 1.0, 4.0}, sse, c[6];
         set_weights_ml(sc, pr);
         const int it = ml_estimate(p, sc, pr, 0, n_valid, sse);
+        if (ml_covariance_throws(sc, pr, 0, n_valid, sse)) return ST_UPDATE_SKIPPED; /* reference: abort */
         ml_covariance(p, sc, pr, sse, c);
         tg.pos[0] = p[0]; tg.pos[1] = p[1]; tg.pos[2] = p[2];
         const double cm[3][3] = {{c[0], c[1], c[2]}, {c[1], c[3], c[4]}, {c[2], c[4], c[5]}};
@@ -616,6 +631,7 @@ KFPOS_FN uint32_t step_toa6(Tag6<SYMM> &tg, SC &sc, const Params &pr, double dt)
     const bool heuristic = n_valid > 4 && pr.ignore_worst;
     int i = 0, best_a = -1, best_i = -1;
     double cost_all = 0.0, max_distance = 0.0, worst_cost = 0.0;
+    bool thrown = false; /* one of the solves hit the reference's std::runtime_error */
     for (int v = pr.ignore_worst ? -1 : A; v <= A; ++v) {
         const bool last = (v == A);
         double ra = 0.0;
@@ -636,6 +652,8 @@ KFPOS_FN uint32_t step_toa6(Tag6<SYMM> &tg, SC &sc, const Params &pr, double dt)
             predict6(tg.P, dt, pr.accel_noise);
             predicted = true;
         }
+        thrown = thrown || (o.flags & ST_UPDATE_SKIPPED);
+        if (thrown) continue; /* the exception leaves kalmanStep3D*: nothing after it runs */
         iekf6(xhat_p, tg.P, sc, pr, mask, 10, 1e-3, o);
         if (last) break;
         if (v < 0) {
@@ -653,6 +671,7 @@ KFPOS_FN uint32_t step_toa6(Tag6<SYMM> &tg, SC &sc, const Params &pr, double dt)
             ++i;
         }
     }
+    if (thrown) return ST_UPDATE_SKIPPED; /* predicted covariance kept, position untouched (:151-153) */
     cov_update6(tg.P, o.mlast);
     tg.pos[0] = o.p[0]; tg.pos[1] = o.p[1]; tg.pos[2] = o.p[2];
     return pack_status(o.flags, o.gain_iters, o.ml_iters, ignored);
@@ -812,6 +831,7 @@ KFPOS_FN void iekf9_weights(const double xhat[9], SC &sc, const Params &pr, bool
         double pml[3] = {xhat[0], xhat[1], xhat[2]}, e_ml;
         set_weights_ml(sc, pr);
         o.ml_iters = ml_estimate(pml, sc, pr, 0ull, n_used, e_ml); /* no NaN fallback in this filter */
+        if (ml_covariance_throws(sc, pr, 0ull, n_used, e_ml)) o.flags |= ST_UPDATE_SKIPPED;
         set_weights_iekf(sc, pr, e_ml);
     }
 }
@@ -981,6 +1001,7 @@ KFPOS_FN uint32_t step_imu9(Tag9 &tg, SC &sc, const Params &pr, double dt,
         double p[3] = {1.0, 1.0, 4.0}, sse, c[6];
         set_weights_ml(sc, pr);
         const int it = ml_estimate(p, sc, pr, 0, n_valid, sse);
+        if (ml_covariance_throws(sc, pr, 0, n_valid, sse)) return ST_UPDATE_SKIPPED; /* reference: abort */
         ml_covariance(p, sc, pr, sse, c);
         tg.pos[0] = p[0]; tg.pos[1] = p[1]; tg.pos[2] = p[2];
         tg.P(0, 0) = c[0]; tg.P(0, 1) = c[1]; tg.P(1, 1) = c[3]; /* xy block only, :134-137 */
@@ -997,6 +1018,9 @@ KFPOS_FN uint32_t step_imu9(Tag9 &tg, SC &sc, const Params &pr, double dt,
     Iekf9Out o;
     iekf9_weights(xhat, sc, pr, has_ranging, n_valid, o); /* needs position + epoch only ... */
     predict9(tg.P, dt, pr.jolt);                          /* ... so the covariance is first touched here */
+    /* The 9-state filter has no try/catch: the reference node aborts here. This core keeps the predicted
+     * covariance and reports the tag instead. */
+    if (o.flags & ST_UPDATE_SKIPPED) return ST_UPDATE_SKIPPED;
     iekf9(xhat, tg.P, sc, pr, has_ranging, imu, 20, 1e-4, o);
     cov_update9(tg.P, o.mrlast, o.dlast, imu);
     KFPOS_UNROLL

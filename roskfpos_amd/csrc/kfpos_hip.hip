@@ -75,10 +75,17 @@ struct KArgs {
     double dt_steps[KFPOS_TRACE_CHUNK];
 };
 
+/* Component-major arrays are addressed as (wave-uniform row base) + (32-bit lane offset): the row base
+ * stays in SGPRs (global_load ... v_off, s[base]) and one VGPR serves every array, instead of a 64-bit
+ * per-lane address kept alive for each of the 30-60 rows between the loads and the final stores. */
 template <typename REAL>
-__device__ inline double ld(const void *p, size_t i) { return (double)((const REAL *)p)[i]; }
+__device__ inline double ldrow(const void *p, size_t row, size_t T, uint32_t t) {
+    return (double)(((const REAL *)p) + row * T)[t];
+}
 template <typename REAL>
-__device__ inline void st(void *p, size_t i, double v) { ((REAL *)p)[i] = (REAL)v; }
+__device__ inline void strow(void *p, size_t row, size_t T, uint32_t t, double v) {
+    (((REAL *)p) + row * T)[t] = (REAL)v;
+}
 
 __device__ inline Params make_params(const KArgs &a) {
     Params pr;
@@ -106,8 +113,8 @@ __device__ inline void fetch_epoch(const KArgs &a, size_t t, int s, RawEpoch<MRE
     const MREAL *ep = (const MREAL *)a.err + (size_t)s * a.stride_err;
 #pragma unroll
     for (int k = 0; k < AS; ++k) { /* all loads first: one latency, not AS of them */
-        raw.mm[k] = rp[(size_t)k * a.T + t];
-        raw.e[k] = ep[(size_t)k * a.T + t];
+        raw.mm[k] = (rp + (size_t)k * a.T)[(uint32_t)t];
+        raw.e[k] = (ep + (size_t)k * a.T)[(uint32_t)t];
     }
 }
 template <typename MREAL, int AS>
@@ -130,9 +137,9 @@ __device__ inline Scratch stage_epoch_lds(const KArgs &a, double *lds, int lane,
     const int32_t *rp = a.ranges + (size_t)s * a.stride_ranges;
     const MREAL *ep = (const MREAL *)a.err + (size_t)s * a.stride_err;
     for (int k = 0; k < a.A; ++k) {
-        const int32_t mm = rp[(size_t)k * a.T + t];
+        const int32_t mm = (rp + (size_t)k * a.T)[(uint32_t)t];
         sc.r[k * WAVE] = mm > 0 ? kf_mm_to_m(mm) : 0.0;
-        sc.e[k * WAVE] = (double)ep[(size_t)k * a.T + t];
+        sc.e[k * WAVE] = (double)(ep + (size_t)k * a.T)[(uint32_t)t];
     }
     return sc;
 }
@@ -148,8 +155,13 @@ __global__ __launch_bounds__(WAVE) void k_step_toa6(const KArgs a) {
     const size_t t = (size_t)blockIdx.x * WAVE + lane;
     if (t >= (size_t)a.T) return;
     const size_t T = a.T;
+    const uint32_t t32 = (uint32_t)t;
     const Params pr = make_params(a);
     constexpr int NA = AS > 0 ? AS : 1;
+    if (a.n_steps == 1 && a.dt && a.dt[t] < 0.0) { /* no epoch for this tag in this call */
+        if (a.status) a.status[t] = ST_SKIPPED;
+        return;
+    }
 
     /* Load order = order of first use: epoch and position feed the ML solve, the covariance is first
      * touched after it (step_toa6), so its 21-36 loads stay in flight behind ~2-3 k instructions. */
@@ -157,9 +169,9 @@ __global__ __launch_bounds__(WAVE) void k_step_toa6(const KArgs a) {
     if constexpr (AS > 0) fetch_epoch<MREAL, AS>(a, t, 0, raw);
     Tag6<SYMM> tg;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) tg.pos[k] = a.pos[k * T + t];
+    for (int k = 0; k < 3; ++k) tg.pos[k] = (a.pos + k * T)[t32];
 #pragma unroll
-    for (int k = 0; k < Cov<6, SYMM>::SZ; ++k) tg.P.a[k] = ld<REAL>(a.P, k * T + t);
+    for (int k = 0; k < Cov<6, SYMM>::SZ; ++k) tg.P.a[k] = ldrow<REAL>(a.P, k, T, t32);
 
     uint32_t s = 0;
     for (int e = 0; e < a.n_steps; ++e) { /* the state stays in registers from epoch to epoch */
@@ -175,7 +187,7 @@ __global__ __launch_bounds__(WAVE) void k_step_toa6(const KArgs a) {
         }
         if (a.traj) { /* the pose a per-epoch caller would have read back (getPose at timeLag 0) */
 #pragma unroll
-            for (int k = 0; k < 3; ++k) a.traj[((size_t)e * 3 + k) * T + t] = tg.pos[k];
+            for (int k = 0; k < 3; ++k) (a.traj + ((size_t)e * 3 + k) * T)[t32] = tg.pos[k];
         }
         if constexpr (sizeof(REAL) == 4) { /* what n single-epoch launches would have kept in HBM */
             if (e + 1 < a.n_steps) {
@@ -188,12 +200,12 @@ __global__ __launch_bounds__(WAVE) void k_step_toa6(const KArgs a) {
     bool fin = true;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        a.pos[k * T + t] = tg.pos[k];
+        (a.pos + k * T)[t32] = tg.pos[k];
         fin &= isfinite(tg.pos[k]);
     }
 #pragma unroll
     for (int k = 0; k < Cov<6, SYMM>::SZ; ++k) {
-        st<REAL>(a.P, k * T + t, tg.P.a[k]);
+        strow<REAL>(a.P, k, T, t32, tg.P.a[k]);
         fin &= isfinite(tg.P.a[k]);
     }
     const bool waiting = !a.use_init_pos && isnan(tg.pos[0]); /* still waiting for its ML initialisation */
@@ -212,9 +224,9 @@ __device__ inline void fetch_imu(const KArgs &a, size_t t, int s, RawImu<MREAL> 
     const MREAL *ap = (const MREAL *)a.accel + (size_t)s * a.stride_accel;
     const MREAL *cp = (const MREAL *)a.cov + (size_t)s * a.stride_cov;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) raw.acc[k] = ap[(size_t)k * a.T + t];
+    for (int k = 0; k < 3; ++k) raw.acc[k] = (ap + (size_t)k * a.T)[(uint32_t)t];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) raw.cov[k] = cp[(size_t)k * a.T + t];
+    for (int k = 0; k < 9; ++k) raw.cov[k] = (cp + (size_t)k * a.T)[(uint32_t)t];
 }
 
 template <typename REAL, typename MREAL, int AS>
@@ -224,10 +236,15 @@ __global__ __launch_bounds__(WAVE) void k_step_imu9(const KArgs a) {
     const size_t t = (size_t)blockIdx.x * WAVE + lane;
     if (t >= (size_t)a.T) return;
     const size_t T = a.T;
+    const uint32_t t32 = (uint32_t)t;
     const Params pr = make_params(a);
     const bool has_ranging = a.mode != MODE_IMU_ONLY;
     const bool fresh_imu = a.mode != MODE_TOA;
     constexpr int NA = AS > 0 ? AS : 1;
+    if (a.n_steps == 1 && a.dt && a.dt[t] < 0.0) { /* no epoch / sample for this tag in this call */
+        if (a.status) a.status[t] = ST_SKIPPED;
+        return;
+    }
 
     /* load order = order of first use (see k_step_toa6): epoch, position, velocity, IMU sample, then the
      * 45 covariance entries, which are not needed until the ML solve is over */
@@ -239,8 +256,8 @@ __global__ __launch_bounds__(WAVE) void k_step_imu9(const KArgs a) {
     Tag9 tg;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        tg.pos[k] = a.pos[k * T + t];
-        tg.vel[k] = a.vel[k * T + t];
+        tg.pos[k] = (a.pos + k * T)[t32];
+        tg.vel[k] = (a.vel + k * T)[t32];
     }
     uint32_t fl = a.flags[t];
     Imu imu;
@@ -251,16 +268,16 @@ __global__ __launch_bounds__(WAVE) void k_step_imu9(const KArgs a) {
     } else if (fl & FL_HAS_IMU) { /* re-fuse the latched sample (KalmanFilterTOAIMU.cpp:68-72) */
         imu.has = true;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) imu.acc[k] = ld<MREAL>(a.imu_acc, k * T + t);
-        cv[0] = ld<MREAL>(a.imu_cov, 0 * T + t);
-        cv[3] = ld<MREAL>(a.imu_cov, 1 * T + t);
-        cv[4] = ld<MREAL>(a.imu_cov, 2 * T + t);
-        cv[6] = ld<MREAL>(a.imu_cov, 3 * T + t);
-        cv[7] = ld<MREAL>(a.imu_cov, 4 * T + t);
-        cv[8] = ld<MREAL>(a.imu_cov, 5 * T + t);
+        for (int k = 0; k < 3; ++k) imu.acc[k] = ldrow<MREAL>(a.imu_acc, k, T, t32);
+        cv[0] = ldrow<MREAL>(a.imu_cov, 0, T, t32);
+        cv[3] = ldrow<MREAL>(a.imu_cov, 1, T, t32);
+        cv[4] = ldrow<MREAL>(a.imu_cov, 2, T, t32);
+        cv[6] = ldrow<MREAL>(a.imu_cov, 3, T, t32);
+        cv[7] = ldrow<MREAL>(a.imu_cov, 4, T, t32);
+        cv[8] = ldrow<MREAL>(a.imu_cov, 5, T, t32);
     }
 #pragma unroll
-    for (int k = 0; k < 45; ++k) tg.P.a[k] = ld<REAL>(a.P, k * T + t);
+    for (int k = 0; k < 45; ++k) tg.P.a[k] = ldrow<REAL>(a.P, k, T, t32);
     if (imu.has) imu_whitener(cv, imu.ci, imu.wi);
 
     uint32_t s = 0;
@@ -275,13 +292,13 @@ __global__ __launch_bounds__(WAVE) void k_step_imu9(const KArgs a) {
             imu_whitener(cv, imu.ci, imu.wi);
             if (a.latch && e + 1 == a.n_steps) {
 #pragma unroll
-                for (int k = 0; k < 3; ++k) st<MREAL>(a.imu_acc, k * T + t, imu.acc[k]);
-                st<MREAL>(a.imu_cov, 0 * T + t, cv[0]);
-                st<MREAL>(a.imu_cov, 1 * T + t, cv[3]);
-                st<MREAL>(a.imu_cov, 2 * T + t, cv[4]);
-                st<MREAL>(a.imu_cov, 3 * T + t, cv[6]);
-                st<MREAL>(a.imu_cov, 4 * T + t, cv[7]);
-                st<MREAL>(a.imu_cov, 5 * T + t, cv[8]);
+                for (int k = 0; k < 3; ++k) strow<MREAL>(a.imu_acc, k, T, t32, imu.acc[k]);
+                strow<MREAL>(a.imu_cov, 0, T, t32, cv[0]);
+                strow<MREAL>(a.imu_cov, 1, T, t32, cv[3]);
+                strow<MREAL>(a.imu_cov, 2, T, t32, cv[4]);
+                strow<MREAL>(a.imu_cov, 3, T, t32, cv[6]);
+                strow<MREAL>(a.imu_cov, 4, T, t32, cv[7]);
+                strow<MREAL>(a.imu_cov, 5, T, t32, cv[8]);
                 fl |= FL_HAS_IMU;
             }
             if (e + 1 < a.n_steps) fetch_imu<MREAL>(a, t, e + 1, rawi);
@@ -303,7 +320,7 @@ __global__ __launch_bounds__(WAVE) void k_step_imu9(const KArgs a) {
         }
         if (a.traj) { /* the pose a per-epoch caller would have read back (getPose at timeLag 0) */
 #pragma unroll
-            for (int k = 0; k < 3; ++k) a.traj[((size_t)e * 3 + k) * T + t] = tg.pos[k];
+            for (int k = 0; k < 3; ++k) (a.traj + ((size_t)e * 3 + k) * T)[t32] = tg.pos[k];
         }
         if constexpr (sizeof(REAL) == 4) { /* what n single-epoch launches would have kept in HBM */
             if (e + 1 < a.n_steps) {
@@ -316,13 +333,13 @@ __global__ __launch_bounds__(WAVE) void k_step_imu9(const KArgs a) {
     bool fin = true;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        a.pos[k * T + t] = tg.pos[k];
-        a.vel[k * T + t] = tg.vel[k];
+        (a.pos + k * T)[t32] = tg.pos[k];
+        (a.vel + k * T)[t32] = tg.vel[k];
         fin &= isfinite(tg.pos[k]) & isfinite(tg.vel[k]);
     }
 #pragma unroll
     for (int k = 0; k < 45; ++k) {
-        st<REAL>(a.P, k * T + t, tg.P.a[k]);
+        strow<REAL>(a.P, k, T, t32, tg.P.a[k]);
         fin &= isfinite(tg.P.a[k]);
     }
     const bool waiting = !a.use_init_pos && isnan(tg.pos[0]);
@@ -335,6 +352,7 @@ __global__ __launch_bounds__(WAVE) void k_step_imu9(const KArgs a) {
 struct PoseArgs {
     int T, model, full;
     double accel_noise, jolt, dt_ahead;
+    const double *dt_each; /* [T] per-tag extrapolation time, or null to use dt_ahead */
     const double *pos_in;
     const double *vel_in;
     const void *P;
@@ -348,8 +366,10 @@ __global__ __launch_bounds__(WAVE) void k_get_pose(const PoseArgs a) {
     const size_t t = (size_t)blockIdx.x * WAVE + threadIdx.x;
     if (t >= (size_t)a.T) return;
     const size_t T = a.T;
+    const uint32_t t32 = (uint32_t)t;
     double pos[3], vel[3] = {0, 0, 0}, cov[9];
     uint32_t s = 0;
+    const double ahead = a.dt_each ? a.dt_each[t] : a.dt_ahead;
     if (!(a.flags[t] & FL_STARTED)) {
         s = ST_NOT_STARTED;
 #pragma unroll
@@ -359,29 +379,29 @@ __global__ __launch_bounds__(WAVE) void k_get_pose(const PoseArgs a) {
     } else if (MODEL == 6) {
         Tag6<SYMM> tg;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) tg.pos[k] = a.pos_in[k * T + t];
+        for (int k = 0; k < 3; ++k) tg.pos[k] = (a.pos_in + k * T)[t32];
 #pragma unroll
-        for (int k = 0; k < Cov<6, SYMM>::SZ; ++k) tg.P.a[k] = ld<REAL>(a.P, k * T + t);
-        pose6<SYMM>(tg, a.dt_ahead, a.accel_noise, pos, cov);
+        for (int k = 0; k < Cov<6, SYMM>::SZ; ++k) tg.P.a[k] = ldrow<REAL>(a.P, k, T, t32);
+        pose6<SYMM>(tg, ahead, a.accel_noise, pos, cov);
     } else {
         Tag9 tg;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            tg.pos[k] = a.pos_in[k * T + t];
-            tg.vel[k] = a.vel_in[k * T + t];
+            tg.pos[k] = (a.pos_in + k * T)[t32];
+            tg.vel[k] = (a.vel_in + k * T)[t32];
         }
 #pragma unroll
-        for (int k = 0; k < 45; ++k) tg.P.a[k] = ld<REAL>(a.P, k * T + t);
-        pose9(tg, a.dt_ahead, a.jolt, pos, vel, cov);
+        for (int k = 0; k < 45; ++k) tg.P.a[k] = ldrow<REAL>(a.P, k, T, t32);
+        pose9(tg, ahead, a.jolt, pos, vel, cov);
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        if (a.pos) a.pos[k * T + t] = pos[k];
-        if (a.vel) a.vel[k * T + t] = vel[k];
+        if (a.pos) (a.pos + k * T)[t32] = pos[k];
+        if (a.vel) (a.vel + k * T)[t32] = vel[k];
     }
     if (a.cov) {
 #pragma unroll
-        for (int k = 0; k < 9; ++k) a.cov[k * T + t] = cov[k];
+        for (int k = 0; k < 9; ++k) (a.cov + k * T)[t32] = cov[k];
     }
     if (a.status) a.status[t] = s;
 }
@@ -461,19 +481,16 @@ void fill_args(const kfpos_handle *h, KArgs &a) {
 
 typedef void (*step_kernel_t)(const KArgs);
 
-/* anchor-count specialisations: 8 (BASELINE configs 2-4) and 16 (config 5) keep the epoch in registers;
- * every other count runs the generic LDS-staged kernel (AS = 0) */
-int static_anchors(const kfpos_handle *h) {
-    const int A = h->cfg.max_anchors;
-    if (A == 8) return 8;
-    if (A == 16 && h->cfg.model == KFPOS_MODEL_TOA) return 16;
-    return 0;
-}
+/* Anchor-count specialisation: 8 anchors (BASELINE configs 2-4) keep the epoch in registers; every other
+ * count runs the generic LDS-staged kernel (AS = 0). A 16-anchor specialisation was measured and dropped:
+ * 96 more live registers push the kernel into scratch spills (no faster than the generic kernel on config 5,
+ * 165 vs 170 us) and, on partially filled wavefronts, the spilled build returned wrong, run-to-run
+ * varying positions -- no kernel in this library may use scratch (checked at build time). */
+int static_anchors(const kfpos_handle *h) { return h->cfg.max_anchors == 8 ? 8 : 0; }
 
 template <bool SYMM, typename REAL, typename MREAL>
 step_kernel_t toa6_kernel(int as) {
     if (as == 8) return k_step_toa6<SYMM, REAL, MREAL, 8>;
-    if (as == 16) return k_step_toa6<SYMM, REAL, MREAL, 16>;
     return k_step_toa6<SYMM, REAL, MREAL, 0>;
 }
 template <typename REAL, typename MREAL>
@@ -783,10 +800,11 @@ int kfpos_run_trace_dev(kfpos_handle *h, int32_t n_steps, const int32_t *range_m
     return KFPOS_OK;
 }
 
-int kfpos_get_pose_dev(kfpos_handle *h, double dt_ahead, double *pos, double *cov3x3, double *vel,
-                       uint32_t *status, void *stream) {
+static int launch_pose(kfpos_handle *h, double dt_ahead, const double *dt_each, double *pos, double *cov3x3,
+                       double *vel, uint32_t *status, void *stream) {
     if (!h) return KFPOS_ERR_ARG;
     PoseArgs a;
+    a.dt_each = dt_each;
     a.T = h->cfg.n_tags;
     a.model = h->cfg.model;
     a.full = h->full;
@@ -816,6 +834,11 @@ int kfpos_get_pose_dev(kfpos_handle *h, double dt_ahead, double *pos, double *co
     }
     HIPCHK(hipGetLastError());
     return KFPOS_OK;
+}
+
+int kfpos_get_pose_dev(kfpos_handle *h, double dt_ahead, double *pos, double *cov3x3, double *vel,
+                       uint32_t *status, void *stream) {
+    return launch_pose(h, dt_ahead, nullptr, pos, cov3x3, vel, status, stream);
 }
 
 /* ---- host-buffer API ---- */
@@ -869,12 +892,17 @@ int kfpos_step_toa_imu(kfpos_handle *h, const int32_t *range_mm, const void *err
     return fetch_status(h, status);
 }
 
-int kfpos_get_pose(kfpos_handle *h, double dt_ahead, double *pos, double *cov3x3, double *vel,
-                   uint32_t *status) {
+static int get_pose_host(kfpos_handle *h, double dt_ahead, const double *dt_each, double *pos, double *cov3x3,
+                         double *vel, uint32_t *status) {
     if (!h) return KFPOS_ERR_ARG;
     const size_t T = h->cfg.n_tags;
     double *dp = h->d_out, *dc = h->d_out + 3 * T, *dv = h->d_out + 12 * T;
-    int rc = kfpos_get_pose_dev(h, dt_ahead, dp, dc, dv, h->d_status, nullptr);
+    const double *d_each = nullptr;
+    if (dt_each) {
+        HIPCHK(hipMemcpy(h->d_dt, dt_each, sizeof(double) * T, hipMemcpyHostToDevice));
+        d_each = h->d_dt;
+    }
+    int rc = launch_pose(h, dt_ahead, d_each, dp, dc, dv, h->d_status, nullptr);
     if (rc) return rc;
     HIPCHK(hipDeviceSynchronize());
     if (pos && (rc = stage_out(h, pos, dp, 3))) return rc;
@@ -882,6 +910,17 @@ int kfpos_get_pose(kfpos_handle *h, double dt_ahead, double *pos, double *cov3x3
     if (vel && (rc = stage_out(h, vel, dv, 3))) return rc;
     if (status) HIPCHK(hipMemcpy(status, h->d_status, sizeof(uint32_t) * T, hipMemcpyDeviceToHost));
     return KFPOS_OK;
+}
+
+int kfpos_get_pose(kfpos_handle *h, double dt_ahead, double *pos, double *cov3x3, double *vel,
+                   uint32_t *status) {
+    return get_pose_host(h, dt_ahead, nullptr, pos, cov3x3, vel, status);
+}
+
+int kfpos_get_pose_each(kfpos_handle *h, const double *dt_ahead, double *pos, double *cov3x3, double *vel,
+                        uint32_t *status) {
+    if (!dt_ahead) return KFPOS_ERR_ARG;
+    return get_pose_host(h, 0.0, dt_ahead, pos, cov3x3, vel, status);
 }
 
 int kfpos_get_state(kfpos_handle *h, double *x, double *P, uint32_t *flags) {

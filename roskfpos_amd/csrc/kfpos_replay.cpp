@@ -25,6 +25,7 @@
 #include <string>
 
 #include "kfpos_adaptor.h"
+#include "kfpos_ingest.h"
 
 using namespace kfpos_host;
 
@@ -36,6 +37,7 @@ struct NodeParams { /* names and defaults: node_pos.cpp:48-109, kfpos_toa.launch
     double initPositionX = 0, initPositionY = 0, initPositionZ = 0;
     int useHeuristicIgnoreWorst = 0;
     double heuristicIgnoreThreshold = 0.5;
+    std::string tagIds = ""; /* not a reference parameter: comma-separated hex tag ids -> batched multi-tag mode */
 };
 
 static bool set_param(NodeParams &p, const std::string &k, const std::string &v) {
@@ -49,6 +51,7 @@ static bool set_param(NodeParams &p, const std::string &k, const std::string &v)
     else if (k == "initPositionZ") p.initPositionZ = atof(v.c_str());
     else if (k == "useHeuristicIgnoreWorst") p.useHeuristicIgnoreWorst = atoi(v.c_str());
     else if (k == "heuristicIgnoreThreshold") p.heuristicIgnoreThreshold = atof(v.c_str());
+    else if (k == "tagIds") p.tagIds = v;
     else return false;
     return true;
 }
@@ -118,6 +121,82 @@ struct EpochAssembler {
     }
 };
 
+/* Batched mode (tagIds:=...): every listed tag gets a row of ONE GPU handle; messages go through
+ * kfpos_ingest.h's BatchedRangingNode, 'F'/'P' lines advance time (timers + GPU rounds), 'P' prints one
+ * line per tag: "P <t> <tagId> <ok> <x> <y> <z> <cov00> <cov11> <cov22>". IMU lines are ignored here. */
+static int run_batched(const NodeParams &p, const std::string &trace) {
+    std::vector<int> tagIds;
+    {
+        std::stringstream ss(p.tagIds);
+        std::string tok;
+        while (std::getline(ss, tok, ',')) tagIds.push_back((int)strtol(tok.c_str(), nullptr, 16));
+    }
+    const int T = (int)tagIds.size();
+    std::vector<int> anchorIds;
+    std::vector<double> anchorXyz;
+    kfpos_handle *h = nullptr;
+    std::unique_ptr<BatchedRangingNode> node;
+    auto ensure = [&]() {
+        if (node) return;
+        kfpos_config c;
+        std::memset(&c, 0, sizeof(c));
+        c.model = p.algorithm == "ALGORITHM_KF_TOA_IMU" ? KFPOS_MODEL_TOA_IMU : KFPOS_MODEL_TOA;
+        c.n_tags = T;
+        c.max_anchors = (int)anchorIds.size();
+        c.storage = KFPOS_STORE_F64;
+        c.accel_noise = p.accelNoise;
+        c.jolt = p.jolt;
+        c.ignore_worst = (c.model == KFPOS_MODEL_TOA) ? p.useHeuristicIgnoreWorst : 0;
+        c.cost_threshold = p.heuristicIgnoreThreshold;
+        /* same (inverted for KF_TOA) start-position rule as the single-tag factory above */
+        const bool fixed = (c.model == KFPOS_MODEL_TOA) ? !p.useStartPosition : (p.useStartPosition != 0);
+        c.use_init_pos = fixed ? 1 : 0;
+        c.init_pos[0] = p.initPositionX; c.init_pos[1] = p.initPositionY; c.init_pos[2] = p.initPositionZ;
+        if (kfpos_create(&c, &h) != KFPOS_OK) throw std::runtime_error(std::string("kfpos_create: ") + kfpos_last_error());
+        kfpos_set_anchors(h, anchorXyz.data(), anchorIds.data(), (int)anchorIds.size());
+        node.reset(new BatchedRangingNode(h, tagIds, anchorIds));
+    };
+    std::ifstream in(trace);
+    std::string line;
+    while (std::getline(in, line)) {
+        if (line.empty() || line[0] == '#') continue;
+        std::istringstream ss(line);
+        char kind;
+        ss >> kind;
+        if (kind == 'A' && !node) {
+            int id; double x, y, z;
+            ss >> id >> x >> y >> z;
+            anchorIds.push_back(id);
+            anchorXyz.push_back(x); anchorXyz.push_back(y); anchorXyz.push_back(z);
+        } else if (kind == 'R') {
+            int anchorId, tag, seq; double t, mm, e;
+            ss >> t >> anchorId >> tag >> mm >> seq >> e;
+            ensure();
+            node->onRanging(t, anchorId, tag, mm, e, seq);
+        } else if (kind == 'F') {
+            double t; ss >> t;
+            ensure();
+            node->poll(t);
+        } else if (kind == 'P') {
+            double t; ss >> t;
+            ensure();
+            node->poll(t);
+            std::vector<double> ahead(T), pos(3 * T), cov(9 * T), vel(3 * T);
+            std::vector<uint32_t> st(T);
+            for (int r = 0; r < T; ++r) ahead[r] = node->sinceLastEstimate(r, t);
+            if (kfpos_get_pose_each(h, ahead.data(), pos.data(), cov.data(), vel.data(), st.data()) != KFPOS_OK)
+                throw std::runtime_error(std::string("kfpos_get_pose_each: ") + kfpos_last_error());
+            for (int r = 0; r < T; ++r)
+                printf("P %.9f %x %d %.17g %.17g %.17g %.17g %.17g %.17g\n", t, tagIds[r],
+                       (st[r] & KFPOS_ST_NOT_STARTED) ? 0 : 1, pos[3 * r], pos[3 * r + 1], pos[3 * r + 2],
+                       cov[9 * r], cov[9 * r + 4], cov[9 * r + 8]);
+        }
+    }
+    node.reset();
+    if (h) kfpos_destroy(h);
+    return 0;
+}
+
 int main(int argc, char **argv) {
     NodeParams p;
     std::string trace;
@@ -133,6 +212,14 @@ int main(int argc, char **argv) {
     if (trace.empty()) {
         fprintf(stderr, "usage: kfpos_replay [name:=value ...] trace.txt\n");
         return 2;
+    }
+    if (!p.tagIds.empty()) {
+        try {
+            return run_batched(p, trace);
+        } catch (const std::exception &e) {
+            fprintf(stderr, "kfpos_replay: %s\n", e.what());
+            return 1;
+        }
     }
     int tagId = 0; /* hex parse, default 0 (node_pos.cpp:139-144) */
     if (!p.toaTagId.empty()) tagId = (int)strtol(p.toaTagId.c_str(), nullptr, 16);

@@ -18,13 +18,14 @@ MODEL_TOA, MODEL_TOA_IMU = 0, 1
 
 class Case:
     def __init__(self, name, model, A, fixed=True, ignore_worst=False, top_n=0, outlier=False,
-                 T=48, S=80, imu_every=1, separate_imu=False, cov_full=False):
+                 T=48, S=80, imu_every=1, separate_imu=False, cov_full=False, zero_err=False):
         self.name, self.model, self.A, self.fixed = name, model, A, fixed
         self.ignore_worst, self.top_n, self.outlier = ignore_worst, top_n, outlier
         self.T, self.S = T, S
         self.imu_every = imu_every        # a fresh IMU sample every k-th epoch (others re-fuse the latch)
         self.separate_imu = separate_imu  # IMU samples arrive as their own step with dt > 0
         self.cov_full = cov_full          # IMU covariance with off-diagonal terms
+        self.zero_err = zero_err          # errorEstimation == 0 for one anchor of every 4th tag: ML goes NaN
 
     def workload(self):
         return Workload(self.T, self.A)
@@ -61,6 +62,9 @@ CASES = [
     Case("imu9_A8_latched", MODEL_TOA_IMU, 8, imu_every=3, cov_full=True),
     Case("imu9_A8_separate", MODEL_TOA_IMU, 8, separate_imu=True),
     # anchor counts without a specialised kernel: the generic LDS-staged path (64 = MAX_NUM_ANCS needs 96 KB of LDS)
+    # errorEstimation 0 (a message "without error estimation", Posgenerator.cpp:95): 1/0 weights make the ML
+    # solve NaN and the 6-state filter falls back to the predicted position (KalmanFilterTOA.cpp:270-272)
+    Case("toa6_A8_zero_err", MODEL_TOA, 8, T=24, S=40, zero_err=True),
     Case("toa6_A5_generic", MODEL_TOA, 5, T=24, S=40),
     Case("imu9_A12_generic", MODEL_TOA_IMU, 12, T=24, S=40),
     Case("toa6_A64_generic", MODEL_TOA, 64, T=24, S=30, ignore_worst=True, outlier=True),
@@ -82,6 +86,8 @@ def drive(case, make_filter, real=np.float64, steps=None, record=False):
     init = w.init_positions() if case.fixed else None
     f = make_filter(case, w, init)
     err = w.err_est().astype(real).astype(np.float64)
+    if case.zero_err:
+        err[::4, 3] = 0.0
     cov = case.accel_cov(w).astype(real).astype(np.float64)
     S = steps or case.S
     pos_hist, st_hist = [], []
