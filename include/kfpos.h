@@ -142,6 +142,13 @@ int kfpos_get_pose(kfpos_handle *h, double dt_ahead, double *pos, double *cov3x3
 int kfpos_get_pose_each(kfpos_handle *h, const double *dt_ahead, double *pos, double *cov3x3, double *vel,
                         uint32_t *status);
 
+/* The whole predict-only extrapolation getPose computes before stateToPose thins it out
+ * (KalmanFilterTOA.cpp:455-468, KalmanFilterTOAIMU.cpp:492-506): x n_tags x n, P n_tags x n x n row-major,
+ * double; dt_len = 1 (shared) or n_tags. Tags without a measurement yet report KFPOS_ST_NOT_STARTED.
+ * Used by the adaptor to fill Vector3::covarianceMatrix exactly as stateToPose does. */
+int kfpos_get_predicted(kfpos_handle *h, const double *dt_ahead, int32_t dt_len, double *x, double *P,
+                        uint32_t *status);
+
 /* Raw filter members for tests and checkpoint/restore: x n_tags x n ([p, v(, a = 0)]),
  * P n_tags x n x n row-major, double. n = kfpos_state_dim(). flags: n_tags words (bit 0 started,
  * bit 1 has latched IMU), may be NULL. */

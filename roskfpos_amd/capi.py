@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_DIR, "csrc", "libkfpos_hip.so")
+LIB_PATH = os.environ.get("KFPOS_LIB_PATH") or os.path.join(_DIR, "csrc", "libkfpos_hip.so")  # override: A/B builds
 
 MODEL_TOA, MODEL_TOA_IMU = 0, 1
 STORE_F64, STORE_F32, STORE_MIXED = 0, 1, 2
@@ -25,7 +25,7 @@ ST_SKIPPED = 64
 EXPORTS = [
     "kfpos_create", "kfpos_destroy", "kfpos_init", "kfpos_set_anchors", "kfpos_set_init_positions",
     "kfpos_real_size", "kfpos_step_toa", "kfpos_step_imu", "kfpos_step_toa_imu", "kfpos_get_pose",
-    "kfpos_get_pose_each",
+    "kfpos_get_pose_each", "kfpos_get_predicted",
     "kfpos_state_dim", "kfpos_get_state", "kfpos_set_state", "kfpos_step_toa_dev", "kfpos_step_imu_dev",
     "kfpos_step_toa_imu_dev", "kfpos_get_pose_dev", "kfpos_run_trace_dev", "kfpos_last_error",
     "kfpos_strerror", "kfpos_version", "kfpos_timing_begin", "kfpos_timing_end",
@@ -74,6 +74,7 @@ def load():
     L.kfpos_step_toa_imu.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp]
     L.kfpos_get_pose.argtypes = [vp, f64, vp, vp, vp, vp]
     L.kfpos_get_pose_each.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.kfpos_get_predicted.argtypes = [vp, vp, i32, vp, vp, vp]
     L.kfpos_get_state.argtypes = [vp, vp, vp, vp]
     L.kfpos_set_state.argtypes = [vp, vp, vp, vp]
     L.kfpos_step_toa_dev.argtypes = [vp, vp, vp, vp, f64, vp, vp]
@@ -204,6 +205,15 @@ class KfposBank:
         self._chk(self.lib.kfpos_get_pose_each(self._h, d.ctypes.data, pos.ctypes.data, cov.ctypes.data,
                                                vel.ctypes.data, st.ctypes.data))
         return pos, cov.reshape(self.T, 3, 3), vel, st
+
+    def get_predicted(self, dt_ahead):
+        d = np.atleast_1d(np.ascontiguousarray(dt_ahead, dtype=np.float64))
+        assert d.size in (1, self.T)
+        x, P = np.zeros((self.T, self.n)), np.zeros((self.T, self.n, self.n))
+        st = np.zeros(self.T, dtype=np.uint32)
+        self._chk(self.lib.kfpos_get_predicted(self._h, d.ctypes.data, d.size, x.ctypes.data, P.ctypes.data,
+                                               st.ctypes.data))
+        return x, P, st
 
     def get_state(self):
         x, P = np.zeros((self.T, self.n)), np.zeros((self.T, self.n, self.n))

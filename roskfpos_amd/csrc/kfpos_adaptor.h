@@ -103,10 +103,10 @@ public:
     bool getPose(Vector3 &pose) override {
         if (!started_) return false; /* KalmanFilterTOA.cpp:442-447 */
         const double ahead = clock_() - last_;
-        double pos[3], cov[9], vel[3];
+        double x[9], P[81];
         uint32_t st = 0;
-        check(kfpos_get_pose(h_, ahead, pos, cov, vel, &st));
-        fillPose(pose, pos, cov, vel, ahead);
+        check(kfpos_get_predicted(h_, &ahead, 1, x, P, &st)); /* predicted state and covariance, :455-468 */
+        fillPose(pose, x, P);
         return true;
     }
 
@@ -140,8 +140,8 @@ protected:
         if (rc != KFPOS_OK)
             throw std::runtime_error(std::string("kfpos: ") + kfpos_strerror(rc) + " " + kfpos_last_error());
     }
-    virtual void fillPose(Vector3 &pose, const double pos[3], const double cov[9], const double vel[3],
-                          double ahead) = 0;
+    /* stateToPose: x = predicted state (n), P = predicted covariance (n x n row-major) */
+    virtual void fillPose(Vector3 &pose, const double *x, const double *P) = 0;
 
     kfpos_handle *h_ = nullptr;
     Clock clock_;
@@ -162,12 +162,12 @@ public:
                           true, &initialPosition) {}
     /* the other four sensors are no-ops in this filter (KalmanFilterTOA.cpp:63-66) */
 protected:
-    void fillPose(Vector3 &pose, const double pos[3], const double cov[9], const double *, double) override {
+    void fillPose(Vector3 &pose, const double *x, const double *P) override {
         pose = Vector3(); /* stateToPose, KalmanFilterTOA.cpp:159-183: zero quaternion, 6x6 with the position block */
-        pose.x = pos[0]; pose.y = pos[1]; pose.z = pos[2];
+        pose.x = x[0]; pose.y = x[1]; pose.z = x[2];
         pose.covarianceDim = 6;
         for (int i = 0; i < 3; ++i)
-            for (int j = 0; j < 3; ++j) pose.covarianceMatrix[i * 6 + j] = cov[3 * i + j];
+            for (int j = 0; j < 3; ++j) pose.covarianceMatrix[i * 6 + j] = P[i * 6 + j];
     }
 };
 
@@ -189,18 +189,22 @@ public:
     }
 
 protected:
-    void fillPose(Vector3 &pose, const double pos[3], const double cov[9], const double vel[3],
-                  double) override {
+    void fillPose(Vector3 &pose, const double *x, const double *P) override {
         pose = Vector3(); /* stateToPose, KalmanFilterTOAIMU.cpp:198-240 */
-        pose.x = pos[0]; pose.y = pos[1]; pose.z = pos[2];
-        pose.linearSpeedX = vel[0]; pose.linearSpeedY = vel[1]; pose.linearSpeedZ = vel[2];
-        /* angularSpeed* carry the acceleration state, which the filter never persists: 0 (:213-215) */
+        pose.x = x[0]; pose.y = x[1]; pose.z = x[2];
+        pose.linearSpeedX = x[3]; pose.linearSpeedY = x[4]; pose.linearSpeedZ = x[5];
+        /* sic: the acceleration state is reported in the angularSpeed fields (:213-215); it is never
+         * persisted, so the predicted value is 0 */
+        pose.angularSpeedX = x[6]; pose.angularSpeedY = x[7]; pose.angularSpeedZ = x[8];
         pose.covarianceDim = 9;
         for (int i = 0; i < 9; ++i) pose.covarianceMatrix[i * 9 + i] = 0.01; /* eye(9,9) * 0.01, :217 */
         for (int i = 0; i < 3; ++i)
-            for (int j = 0; j < 3; ++j) pose.covarianceMatrix[i * 9 + j] = cov[3 * i + j];
-        /* :231-239 also copy P(0..2,8) / P(8,8) into row/column 7; not exposed by kfpos_get_pose and
-         * never read by PosGenerator, which forwards the first 36 linear elements (Posgenerator.cpp:397-399) */
+            for (int j = 0; j < 3; ++j) pose.covarianceMatrix[i * 9 + j] = P[i * 9 + j];
+        for (int i = 0; i < 3; ++i) { /* sic: row/column 7 receive P(.,8) (:231-239) */
+            pose.covarianceMatrix[i * 9 + 7] = P[i * 9 + 8];
+            pose.covarianceMatrix[7 * 9 + i] = P[8 * 9 + i];
+        }
+        pose.covarianceMatrix[7 * 9 + 7] = P[8 * 9 + 8];
     }
 };
 

@@ -358,6 +358,7 @@ struct PoseArgs {
     const void *P;
     const uint32_t *flags;
     double *pos, *cov, *vel; /* [3][T], [9][T], [3][T]; any may be null */
+    double *full_x, *full_P; /* [n][T], [n*n][T] predicted state / covariance (row-major index first), or null */
     uint32_t *status;
 };
 
@@ -376,6 +377,12 @@ __global__ __launch_bounds__(WAVE) void k_get_pose(const PoseArgs a) {
         for (int k = 0; k < 3; ++k) pos[k] = vel[k] = NAN;
 #pragma unroll
         for (int k = 0; k < 9; ++k) cov[k] = NAN;
+        if (a.full_P) {
+            constexpr int N = MODEL == 6 ? 6 : 9;
+#pragma unroll
+            for (int i = 0; i < N; ++i) (a.full_x + i * T)[t32] = NAN;
+            for (int i = 0; i < N * N; ++i) (a.full_P + (size_t)i * T)[t32] = NAN;
+        }
     } else if (MODEL == 6) {
         Tag6<SYMM> tg;
 #pragma unroll
@@ -383,6 +390,15 @@ __global__ __launch_bounds__(WAVE) void k_get_pose(const PoseArgs a) {
 #pragma unroll
         for (int k = 0; k < Cov<6, SYMM>::SZ; ++k) tg.P.a[k] = ldrow<REAL>(a.P, k, T, t32);
         pose6<SYMM>(tg, ahead, a.accel_noise, pos, cov);
+        if (a.full_P) { /* the whole predicted covariance, as getPose computes it (KalmanFilterTOA.cpp:467-468) */
+            predict6(tg.P, ahead, a.accel_noise);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                (a.full_x + i * T)[t32] = i < 3 ? tg.pos[i] : 0.0;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) (a.full_P + (size_t)(i * 6 + j) * T)[t32] = tg.P(i, j);
+            }
+        }
     } else {
         Tag9 tg;
 #pragma unroll
@@ -393,6 +409,15 @@ __global__ __launch_bounds__(WAVE) void k_get_pose(const PoseArgs a) {
 #pragma unroll
         for (int k = 0; k < 45; ++k) tg.P.a[k] = ldrow<REAL>(a.P, k, T, t32);
         pose9(tg, ahead, a.jolt, pos, vel, cov);
+        if (a.full_P) { /* KalmanFilterTOAIMU.cpp:503-506 */
+            predict9(tg.P, ahead, a.jolt);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                (a.full_x + i * T)[t32] = i < 3 ? pos[i] : (i < 6 ? vel[i - 3] : 0.0);
+#pragma unroll
+                for (int j = 0; j < 9; ++j) (a.full_P + (size_t)(i * 9 + j) * T)[t32] = tg.P(i, j);
+            }
+        }
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -801,10 +826,13 @@ int kfpos_run_trace_dev(kfpos_handle *h, int32_t n_steps, const int32_t *range_m
 }
 
 static int launch_pose(kfpos_handle *h, double dt_ahead, const double *dt_each, double *pos, double *cov3x3,
-                       double *vel, uint32_t *status, void *stream) {
+                       double *vel, uint32_t *status, void *stream, double *full_x = nullptr,
+                       double *full_P = nullptr) {
     if (!h) return KFPOS_ERR_ARG;
     PoseArgs a;
     a.dt_each = dt_each;
+    a.full_x = full_x;
+    a.full_P = full_P;
     a.T = h->cfg.n_tags;
     a.model = h->cfg.model;
     a.full = h->full;
@@ -921,6 +949,35 @@ int kfpos_get_pose_each(kfpos_handle *h, const double *dt_ahead, double *pos, do
                         uint32_t *status) {
     if (!dt_ahead) return KFPOS_ERR_ARG;
     return get_pose_host(h, 0.0, dt_ahead, pos, cov3x3, vel, status);
+}
+
+int kfpos_get_predicted(kfpos_handle *h, const double *dt_ahead, int32_t dt_len, double *x, double *P,
+                        uint32_t *status) {
+    if (!h || !dt_ahead || !x || !P || (dt_len != 1 && dt_len != h->cfg.n_tags)) return KFPOS_ERR_ARG;
+    const size_t T = h->cfg.n_tags, n = h->n;
+    double *dx = nullptr, *dP = nullptr;
+    HIPCHK(hipMalloc((void **)&dx, n * T * sizeof(double)));
+    if (hipMalloc((void **)&dP, n * n * T * sizeof(double)) != hipSuccess) {
+        (void)hipFree(dx);
+        g_err = "hipMalloc failed";
+        return KFPOS_ERR_HIP;
+    }
+    const double *d_each = nullptr;
+    int rc = KFPOS_OK;
+    if (dt_len > 1 || T == 1) {
+        if (hipMemcpy(h->d_dt, dt_ahead, sizeof(double) * T, hipMemcpyHostToDevice) != hipSuccess) rc = KFPOS_ERR_HIP;
+        d_each = h->d_dt;
+    }
+    if (rc == KFPOS_OK) rc = launch_pose(h, dt_ahead[0], d_each, nullptr, nullptr, nullptr, h->d_status, nullptr, dx, dP);
+    if (rc == KFPOS_OK && hipDeviceSynchronize() != hipSuccess) rc = KFPOS_ERR_HIP;
+    if (rc == KFPOS_OK) rc = stage_out(h, x, dx, (int)n);
+    if (rc == KFPOS_OK) rc = stage_out(h, P, dP, (int)(n * n));
+    if (rc == KFPOS_OK && status &&
+        hipMemcpy(status, h->d_status, sizeof(uint32_t) * T, hipMemcpyDeviceToHost) != hipSuccess)
+        rc = KFPOS_ERR_HIP;
+    (void)hipFree(dx);
+    (void)hipFree(dP);
+    return rc;
 }
 
 int kfpos_get_state(kfpos_handle *h, double *x, double *P, uint32_t *flags) {

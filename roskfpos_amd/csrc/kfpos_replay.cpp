@@ -26,6 +26,7 @@
 
 #include "kfpos_adaptor.h"
 #include "kfpos_ingest.h"
+#include "kfpos_publish.h"
 
 using namespace kfpos_host;
 
@@ -37,6 +38,8 @@ struct NodeParams { /* names and defaults: node_pos.cpp:48-109, kfpos_toa.launch
     double initPositionX = 0, initPositionY = 0, initPositionZ = 0;
     int useHeuristicIgnoreWorst = 0;
     double heuristicIgnoreThreshold = 0.5;
+    std::string targetDeviceId = "", nodeName = "/kfpos"; /* topic names, node_pos.cpp:119-135 */
+    int dumpMessages = 0; /* not a reference parameter: print every published message field on P ticks */
     std::string tagIds = ""; /* not a reference parameter: comma-separated hex tag ids -> batched multi-tag mode */
 };
 
@@ -52,6 +55,9 @@ static bool set_param(NodeParams &p, const std::string &k, const std::string &v)
     else if (k == "useHeuristicIgnoreWorst") p.useHeuristicIgnoreWorst = atoi(v.c_str());
     else if (k == "heuristicIgnoreThreshold") p.heuristicIgnoreThreshold = atof(v.c_str());
     else if (k == "tagIds") p.tagIds = v;
+    else if (k == "targetDeviceId") p.targetDeviceId = v;
+    else if (k == "nodeName") p.nodeName = v;
+    else if (k == "dumpMessages") p.dumpMessages = atoi(v.c_str());
     else return false;
     return true;
 }
@@ -230,6 +236,7 @@ int main(int argc, char **argv) {
         alg->setClock([&now] { return now; });
         alg->init();
         EpochAssembler ep;
+        PosePublisher publisher;
         std::ifstream in(trace);
         std::string line;
         while (std::getline(in, line)) {
@@ -257,6 +264,21 @@ int main(int argc, char **argv) {
                 now = t;
                 double cw[9] = {0};
                 alg->newIMUMeasurement(w, cw, a, c);
+            } else if (kind == 'P' && p.dumpMessages) {
+                ss >> now;
+                const bool ok = publisher.fixedRateReport(*alg, now);
+                const Topics tn = topicNames(p.nodeName, p.targetDeviceId);
+                printf("M %.9f %d %s %s %s %s %s %s %zu", now, ok ? 1 : 0, tn.pose.c_str(), tn.path.c_str(),
+                       tn.odom.c_str(), publisher.msg.frame_id.c_str(), publisher.odom.frame_id.c_str(),
+                       publisher.odom.child_frame_id.c_str(), publisher.path.poses.size());
+                if (ok) {
+                    printf(" %.17g %.17g %.17g %.17g", publisher.msg.pose.px, publisher.msg.pose.py,
+                           publisher.msg.pose.pz, publisher.msg.pose.qw);
+                    for (int i = 0; i < 36; ++i) printf(" %.17g", publisher.msg.covariance[i]);
+                    for (int i = 0; i < 3; ++i) printf(" %.17g", publisher.odom.twist_linear[i]);
+                    for (int i = 0; i < 3; ++i) printf(" %.17g", publisher.odom.twist_angular[i]);
+                }
+                printf("\n");
             } else if (kind == 'P') {
                 ss >> now;
                 Vector3 pose;
