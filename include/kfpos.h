@@ -38,6 +38,9 @@ extern "C" {
 /* ---- models: the `algorithm` launch parameter (node_pos.cpp:48-58) ---- */
 #define KFPOS_MODEL_TOA     0 /* ALGORITHM_KF_TOA     -> KalmanFilterTOA, 6 states p,v */
 #define KFPOS_MODEL_TOA_IMU 1 /* ALGORITHM_KF_TOA_IMU -> KalmanFilterTOAIMU, 9 states p,v,a (3-token repair) */
+#define KFPOS_MODEL_ML      2 /* ALGORITHM_ML -> MLLocation as the estimator (MLLocation.cpp:421-486): 3-D, variant NORMAL
+                               (top_n = 0) or IGNORE_N (top_n = numRangingsToIgnore); state = position, P = its 3x3
+                               covariance; dt is ignored, use_init_pos selects the solver's seed ({1,1,4} otherwise) */
 
 /* ---- storage precision of the covariance and of the measurements in HBM; arithmetic is always f64 ----
  * Positions and velocities are kept as double in both modes, ranges are exact integer mm. F32 rounds the

@@ -683,6 +683,40 @@ unsigned toa6_estimate(const Params &pr, Tag &tg, const std::vector<Meas> &allIn
     return pack_status(ns.flags, ns.gainIters, ns.mlIters, ignored);
 }
 
+/* MLLocation as the estimator (ALGORITHM_ML): newTOAMeasurement keeps the epoch (MLLocation.cpp:472-486),
+ * getPose solves it from the never-updated _previousEstimation (:421-469): variant NORMAL 3-D
+ * (estimatePosition) or IGNORE_N (estimatePositionIgnoreN, :307-347, which re-solves on the ranges SORTED by
+ * residual minus the worst min(n-4, N)). The solve is deterministic, so it is done here once per epoch and
+ * kept in the tag: pos = estimate, P (3x3) = its covariance. The 2-D and BestGroup variants are not restated:
+ * getPose indexes (0,2) of the 2x2 covariance of estimatePosition2D, and estimatePositionBestGroup erases
+ * through shifting indices (:379-383), both undefined beyond trivial sizes. */
+unsigned ml_estimator(const Params &pr, Tag &tg, const std::vector<Meas> &all, const double seed3[3]) {
+    tg.started = true;
+    Pos3 seed{seed3[0], seed3[1], seed3[2], Mat()}, est;
+    int it = 0;
+    if ((int)all.size() < 4) { /* the seed comes back with an empty covariance: getPose would index it (abort) */
+        for (int k = 0; k < 3; ++k) tg.pos[k] = seed3[k];
+        for (int k = 0; k < 9; ++k) tg.P[k] = NAN;
+        return KFO_ST_FEW_RANGES;
+    }
+    if (!ml_estimate(all, seed, est, &it)) return KFO_ST_UPDATE_SKIPPED;
+    if (pr.topN > 0) {
+        std::vector<double> d = distances(est, all);
+        std::vector<std::pair<double, int>> q(all.size());
+        for (size_t i = 0; i < all.size(); ++i) q[i] = {(d[i] - all[i].ranging) * (d[i] - all[i].ranging), (int)i};
+        std::sort(q.begin(), q.end(),
+                  [](const std::pair<double, int> &a, const std::pair<double, int> &b) { return a.first < b.first; });
+        std::vector<Meas> kept;
+        for (auto &e : q) kept.push_back(all[e.second]); /* reordered, as the reference does (:327-331) */
+        const int drop = std::min((int)all.size() - 4, pr.topN);
+        for (int k = 0; k < drop; ++k) kept.pop_back();
+        if (!ml_estimate(kept, seed, est, &it)) return KFO_ST_UPDATE_SKIPPED;
+    }
+    tg.pos[0] = est.x; tg.pos[1] = est.y; tg.pos[2] = est.z;
+    for (int k = 0; k < 9; ++k) tg.P[k] = est.cov.a[k];
+    return pack_status(0, 0, it, -1);
+}
+
 /* KalmanFilterTOAIMU::estimatePositionKF, KalmanFilterTOAIMU.cpp:100-195 */
 unsigned imu9_estimate(const Params &pr, Tag &tg, bool hasRanging, const std::vector<Meas> &all,
                        bool hasImu, double timeLag) {
@@ -729,6 +763,7 @@ struct kfo_filter_bank {
     int T, A;
     std::vector<double> anchors;
     std::vector<Tag> tags;
+    std::vector<double> ml_seed; /* ALGORITHM_ML: _previousEstimation per tag */
 };
 
 namespace {
@@ -772,7 +807,7 @@ kfo_filter_bank *kfo_create(int model, int n_tags, int max_anchors, double accel
                             const double *init_pos) {
     kfo_filter_bank *o = new kfo_filter_bank();
     o->pr.model = model;
-    o->pr.n = (model == KFO_MODEL_TOA_IMU) ? 9 : 6;
+    o->pr.n = (model == KFO_MODEL_TOA_IMU) ? 9 : (model == KFO_MODEL_ML ? 3 : 6);
     o->pr.topN = top_n;
     o->pr.accelNoise = accel_noise;
     o->pr.jolt = jolt;
@@ -783,6 +818,9 @@ kfo_filter_bank *kfo_create(int model, int n_tags, int max_anchors, double accel
     o->A = max_anchors;
     o->anchors.assign((size_t)3 * max_anchors, 0.0);
     o->tags.resize(n_tags);
+    o->ml_seed.assign((size_t)3 * n_tags, 0.0);
+    for (int t = 0; t < n_tags; ++t)
+        for (int k = 0; k < 3; ++k) o->ml_seed[3 * (size_t)t + k] = (use_init_pos && init_pos) ? init_pos[3 * t + k] : 0.0;
     for (int t = 0; t < n_tags; ++t) {
         Tag &tg = o->tags[t];
         std::memset(&tg, 0, sizeof(Tag));
@@ -807,6 +845,12 @@ void kfo_step_toa(kfo_filter_bank *o, const int32_t *range_mm, const double *err
             const double lag = dt[dt_len > 1 ? t : 0];
             if (dt_len > 1 && lag < 0) { /* no epoch for this tag: the reference makes no call at all */
                 if (status) status[t] = KFO_ST_SKIPPED;
+                continue;
+            }
+            if (o->pr.model == KFO_MODEL_ML) {
+                const double one14[3] = {1.0, 1.0, 4.0};
+                const unsigned st = ml_estimator(o->pr, tg, m, o->pr.useFixedInit ? &o->ml_seed[3 * (size_t)t] : one14);
+                if (status) status[t] = st;
                 continue;
             }
             unsigned st = (o->pr.n == 6) ? toa6_estimate(o->pr, tg, m, lag)
@@ -843,13 +887,20 @@ void kfo_step_imu(kfo_filter_bank *o, const double *accel, const double *cov, co
 void kfo_get_pose(const kfo_filter_bank *o, double dt_ahead, double *pos, double *cov3x3, double *vel,
                   uint32_t *status) {
     const int n = o->pr.n;
-    const Mat F = pred_F(n, dt_ahead), Q = pred_Q(o->pr, dt_ahead);
+    const bool is_ml = o->pr.model == KFO_MODEL_ML;
+    const Mat F = is_ml ? Mat() : pred_F(n, dt_ahead), Q = is_ml ? Mat() : pred_Q(o->pr, dt_ahead);
     for (int t = 0; t < o->T; ++t) {
         const Tag &tg = o->tags[t];
         if (!tg.started) { /* getPose returns false: pose untouched = NaN (Posgenerator.cpp:542) */
             for (int k = 0; k < 3; ++k) { pos[3 * t + k] = NAN; if (vel) vel[3 * t + k] = NAN; }
             for (int k = 0; k < 9; ++k) cov3x3[9 * t + k] = NAN;
             if (status) status[t] = KFO_ST_NOT_STARTED;
+            continue;
+        }
+        if (o->pr.model == KFO_MODEL_ML) { /* MLLocation::getPose: the estimate and its 3x3 covariance, no motion model */
+            for (int k = 0; k < 3; ++k) { pos[3 * t + k] = tg.pos[k]; if (vel) vel[3 * t + k] = 0.0; }
+            for (int k = 0; k < 9; ++k) cov3x3[9 * t + k] = tg.P[k];
+            if (status) status[t] = 0;
             continue;
         }
         std::vector<double> st(n, 0.0), pred(n, 0.0);

@@ -27,6 +27,7 @@ typedef struct kfo_filter_bank kfo_filter_bank;
 /* model ids follow node_pos.cpp:50-57 (ALGORITHM_KF_TOA / ALGORITHM_KF_TOA_IMU) */
 #define KFO_MODEL_TOA     0 /* KalmanFilterTOA,    6 states */
 #define KFO_MODEL_TOA_IMU 1 /* KalmanFilterTOAIMU, 9 states (with the 3-token repair) */
+#define KFO_MODEL_ML      2 /* MLLocation as a standalone estimator (ALGORITHM_ML), 3-D, variant NORMAL / IGNORE_N */
 
 /* per-tag status bits reported by a step (same layout as include/kfpos.h) */
 #define KFO_ST_UPDATE_SKIPPED 0x01u /* inv/pinv/solve "threw": predicted P kept (KalmanFilterTOA.cpp:151-153) */

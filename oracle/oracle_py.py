@@ -14,7 +14,7 @@ import numpy as np
 _DIR = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_DIR, "libkfpos_oracle.so")
 
-MODEL_TOA, MODEL_TOA_IMU = 0, 1
+MODEL_TOA, MODEL_TOA_IMU, MODEL_ML = 0, 1, 2
 ST_UPDATE_SKIPPED, ST_ML_FALLBACK, ST_FEW_RANGES, ST_ML_INIT, ST_NOT_STARTED, ST_NONFINITE = 1, 2, 4, 8, 16, 32
 
 _dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")

@@ -15,7 +15,7 @@ import numpy as np
 _DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KFPOS_LIB_PATH") or os.path.join(_DIR, "csrc", "libkfpos_hip.so")  # override: A/B builds
 
-MODEL_TOA, MODEL_TOA_IMU = 0, 1
+MODEL_TOA, MODEL_TOA_IMU, MODEL_ML = 0, 1, 2
 STORE_F64, STORE_F32, STORE_MIXED = 0, 1, 2
 MAX_ANCHORS = 64
 ST_UPDATE_SKIPPED, ST_ML_FALLBACK, ST_FEW_RANGES, ST_ML_INIT, ST_NOT_STARTED, ST_NONFINITE = 1, 2, 4, 8, 16, 32

@@ -423,6 +423,57 @@ KFPOS_FN uint64_t topn_mask(const double seed[3], SC &sc, const Params &pr, int 
     return drop;
 }
 
+/* ================================================================== standalone ML estimator (ALGORITHM_ML) */
+/* MLLocation::newTOAMeasurement + getPose (MLLocation.cpp:421-486), variant NORMAL 3-D or IGNORE_N
+ * (estimatePositionIgnoreN, :307-347): solve from the fixed seed (_previousEstimation is never updated),
+ * optionally drop the min(n-4, N) largest residuals and solve again, return position + 3x3 covariance. */
+template <class SC>
+KFPOS_FN uint32_t step_ml(double pos[3], double cov[6], SC &sc, const Params &pr, const double seed[3]) {
+    int n_valid = count_used(sc, pr, 0);
+    if (n_valid < 4) { /* estimatePosition returns the seed; its covariance is empty (getPose would abort) */
+        KFPOS_UNROLL
+        for (int k = 0; k < 3; ++k) pos[k] = seed[k];
+        KFPOS_UNROLL
+        for (int k = 0; k < 6; ++k) cov[k] = NAN;
+        return ST_FEW_RANGES;
+    }
+    uint64_t drop = 0;
+    if (pr.top_n > 0) {
+        drop = topn_mask(seed, sc, pr, n_valid); /* first solve + ranking */
+        /* the first solve throws exactly when a used errorEstimation is 0 (its sse is NaN then) */
+        if (ml_covariance_throws(sc, pr, 0, n_valid, NAN)) return ST_UPDATE_SKIPPED;
+        n_valid = count_used(sc, pr, drop);
+    }
+    double p[3] = {seed[0], seed[1], seed[2]}, sse;
+    set_weights_ml(sc, pr);
+    const int it = ml_estimate(p, sc, pr, drop, n_valid, sse);
+    if (ml_covariance_throws(sc, pr, drop, n_valid, sse)) return ST_UPDATE_SKIPPED;
+    double c[6];
+    /* covariance over the kept ranges only */
+    {
+        double m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0, cf[6];
+        for_anchors<SC>(pr, [&](int a) {
+            const bool on = used(sc, a, drop);
+            const double dx = p[0] - pr.anchors[3 * a], dy = p[1] - pr.anchors[3 * a + 1],
+                         dz = p[2] - pr.anchors[3 * a + 2];
+            const double invd = 1.0 / sqrt(dx * dx + dy * dy + dz * dz);
+            const double w = on ? 1.0 / stdmax(sc.E(a), sse) : 0.0;
+            const double gx = dx * invd, gy = dy * invd, gz = dz * invd;
+            m0 += w * gx * gx; m1 += w * gx * gy; m2 += w * gx * gz;
+            m3 += w * gy * gy; m4 += w * gy * gz; m5 += w * gz * gz;
+        });
+        const double m[6] = {m0, m1, m2, m3, m4, m5};
+        const double idet = 1.0 / sym3_cofactors(m, cf);
+        KFPOS_UNROLL
+        for (int k = 0; k < 6; ++k) c[k] = cf[k] * idet;
+    }
+    KFPOS_UNROLL
+    for (int k = 0; k < 3; ++k) pos[k] = p[k];
+    KFPOS_UNROLL
+    for (int k = 0; k < 6; ++k) cov[k] = c[k];
+    return pack_status(0, 0, it, -1);
+}
+
 /* ================================================================== 6-state filter (KalmanFilterTOA) */
 template <bool SYMM>
 struct Tag6 {

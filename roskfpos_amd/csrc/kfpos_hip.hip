@@ -214,6 +214,54 @@ __global__ __launch_bounds__(WAVE) void k_step_toa6(const KArgs a) {
     if (a.status) a.status[t] = s;
 }
 
+/* ------------------------------------------------------------------ standalone ML estimator kernel */
+template <typename REAL, typename MREAL, int AS>
+__global__ __launch_bounds__(WAVE) void k_step_ml(const KArgs a) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const size_t t = (size_t)blockIdx.x * WAVE + lane;
+    if (t >= (size_t)a.T) return;
+    const size_t T = a.T;
+    const uint32_t t32 = (uint32_t)t;
+    const Params pr = make_params(a);
+    if (a.n_steps == 1 && a.dt && a.dt[t] < 0.0) {
+        if (a.status) a.status[t] = ST_SKIPPED;
+        return;
+    }
+    /* _previousEstimation: the per-tag seed lives in the velocity slot of the handle, it is never updated */
+    double seed[3] = {1.0, 1.0, 4.0};
+    if (a.use_init_pos) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) seed[k] = (a.vel + k * T)[t32];
+    }
+    double pos[3], cov[6];
+    uint32_t s = 0;
+    for (int e = 0; e < a.n_steps; ++e) {
+        if constexpr (AS > 0) {
+            RawEpoch<MREAL, AS> raw;
+            fetch_epoch<MREAL, AS>(a, t, e, raw);
+            RegScratch<AS> sc;
+            unpack_epoch<MREAL, AS>(raw, sc);
+            s = step_ml(pos, cov, sc, pr, seed);
+        } else {
+            Scratch sc = stage_epoch_lds<MREAL>(a, lds, lane, t, e);
+            s = step_ml(pos, cov, sc, pr, seed);
+        }
+        if (a.traj && !(s & ST_UPDATE_SKIPPED)) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) (a.traj + ((size_t)e * 3 + k) * T)[t32] = pos[k];
+        }
+    }
+    if (!(s & ST_UPDATE_SKIPPED)) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) (a.pos + k * T)[t32] = pos[k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) strow<REAL>(a.P, k, T, t32, cov[k]);
+    }
+    a.flags[t] |= FL_STARTED;
+    if (a.status) a.status[t] = s;
+}
+
 /* ------------------------------------------------------------------ 9-state step kernel */
 template <typename MREAL>
 struct RawImu {
@@ -378,10 +426,23 @@ __global__ __launch_bounds__(WAVE) void k_get_pose(const PoseArgs a) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) cov[k] = NAN;
         if (a.full_P) {
-            constexpr int N = MODEL == 6 ? 6 : 9;
+            constexpr int N = MODEL == 6 ? 6 : (MODEL == 3 ? 3 : 9);
 #pragma unroll
             for (int i = 0; i < N; ++i) (a.full_x + i * T)[t32] = NAN;
             for (int i = 0; i < N * N; ++i) (a.full_P + (size_t)i * T)[t32] = NAN;
+        }
+    } else if (MODEL == 3) { /* MLLocation::getPose: the estimate as it is */
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pos[k] = (a.pos_in + k * T)[t32];
+        const double c[6] = {ldrow<REAL>(a.P, 0, T, t32), ldrow<REAL>(a.P, 1, T, t32), ldrow<REAL>(a.P, 2, T, t32),
+                             ldrow<REAL>(a.P, 3, T, t32), ldrow<REAL>(a.P, 4, T, t32), ldrow<REAL>(a.P, 5, T, t32)};
+        cov[0] = c[0]; cov[1] = c[1]; cov[2] = c[2]; cov[3] = c[1]; cov[4] = c[3]; cov[5] = c[4];
+        cov[6] = c[2]; cov[7] = c[4]; cov[8] = c[5];
+        if (a.full_P) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) (a.full_x + i * T)[t32] = pos[i];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) (a.full_P + (size_t)i * T)[t32] = cov[i];
         }
     } else if (MODEL == 6) {
         Tag6<SYMM> tg;
@@ -524,8 +585,17 @@ step_kernel_t imu9_kernel(int as) {
     return k_step_imu9<REAL, MREAL, 0>;
 }
 
+template <typename REAL, typename MREAL>
+step_kernel_t ml_kernel(int as) {
+    if (as == 8) return k_step_ml<REAL, MREAL, 8>;
+    return k_step_ml<REAL, MREAL, 0>;
+}
+
 step_kernel_t step_kernel(const kfpos_handle *h) {
     const int st = h->cfg.storage, as = h->force_generic ? 0 : static_anchors(h);
+    if (h->cfg.model == KFPOS_MODEL_ML)
+        return st == KFPOS_STORE_F32 ? ml_kernel<float, float>(as)
+             : st == KFPOS_STORE_MIXED ? ml_kernel<double, float>(as) : ml_kernel<double, double>(as);
     if (h->cfg.model == KFPOS_MODEL_TOA) {
         if (h->full)
             return st == KFPOS_STORE_F32 ? toa6_kernel<false, float, float>(as)
@@ -617,11 +687,13 @@ int kfpos_version(void) { return KFPOS_VERSION; }
 int kfpos_create(const kfpos_config *cfg, kfpos_handle **out) {
     if (!cfg || !out) return KFPOS_ERR_ARG;
     *out = nullptr;
-    if (cfg->model != KFPOS_MODEL_TOA && cfg->model != KFPOS_MODEL_TOA_IMU) return KFPOS_ERR_ARG;
+    if (cfg->model != KFPOS_MODEL_TOA && cfg->model != KFPOS_MODEL_TOA_IMU && cfg->model != KFPOS_MODEL_ML)
+        return KFPOS_ERR_ARG;
     if (cfg->storage != KFPOS_STORE_F64 && cfg->storage != KFPOS_STORE_F32 && cfg->storage != KFPOS_STORE_MIXED)
         return KFPOS_ERR_ARG;
     if (cfg->n_tags < 1 || cfg->max_anchors < 1 || cfg->max_anchors > KFPOS_MAX_ANCHORS) return KFPOS_ERR_ARG;
-    if (cfg->top_n < 0 || (cfg->model == KFPOS_MODEL_TOA_IMU && (cfg->top_n || cfg->ignore_worst)))
+    if (cfg->top_n < 0 || (cfg->model == KFPOS_MODEL_TOA_IMU && (cfg->top_n || cfg->ignore_worst)) ||
+        (cfg->model == KFPOS_MODEL_ML && cfg->ignore_worst))
         return KFPOS_ERR_ARG; /* both heuristics exist for the 6-state filter only */
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) {
@@ -632,7 +704,7 @@ int kfpos_create(const kfpos_config *cfg, kfpos_handle **out) {
     kfpos_handle *h = new (std::nothrow) kfpos_handle();
     if (!h) return KFPOS_ERR_ARG;
     h->cfg = *cfg;
-    h->n = cfg->model == KFPOS_MODEL_TOA_IMU ? 9 : 6;
+    h->n = cfg->model == KFPOS_MODEL_TOA_IMU ? 9 : (cfg->model == KFPOS_MODEL_ML ? 3 : 6);
     h->full = (cfg->model == KFPOS_MODEL_TOA && !cfg->use_init_pos) ? 1 : 0;
     h->psz = h->full ? h->n * h->n : h->n * (h->n + 1) / 2;
     h->rsz = cfg->storage == KFPOS_STORE_F32 ? 4 : 8;
@@ -662,6 +734,7 @@ int kfpos_create(const kfpos_config *cfg, kfpos_handle **out) {
     ALLOC(h->d_pos, 3 * T * sizeof(double));
     ALLOC(h->d_P, h->psz * T * r);
     ALLOC(h->d_flags, T * sizeof(uint32_t));
+    if (h->n == 3) ALLOC(h->d_vel, 3 * T * sizeof(double)); /* ALGORITHM_ML: the solver's per-tag seed */
     if (h->n == 9) {
         ALLOC(h->d_vel, 3 * T * sizeof(double));
         ALLOC(h->d_imu_acc, 3 * T * m);
@@ -693,6 +766,11 @@ int kfpos_create(const kfpos_config *cfg, kfpos_handle **out) {
     std::vector<double> p0(3 * T);
     for (size_t t = 0; t < T; ++t)
         for (int k = 0; k < 3; ++k) p0[(size_t)k * T + t] = cfg->use_init_pos ? cfg->init_pos[k] : NAN;
+    if (h->n == 3 && hipMemcpy(h->d_vel, p0.data(), p0.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+        g_err = "hipMemcpy(ml seed) failed";
+        kfpos_destroy(h);
+        return KFPOS_ERR_HIP;
+    }
     if (hipMemcpy(h->d_pos, p0.data(), p0.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
         g_err = "hipMemcpy(init pos) failed";
         kfpos_destroy(h);
@@ -729,6 +807,10 @@ int kfpos_set_anchors(kfpos_handle *h, const double *xyz, const int32_t *ids, in
 int kfpos_set_init_positions(kfpos_handle *h, const double *xyz) {
     if (!h || !xyz) return KFPOS_ERR_ARG;
     if (!h->cfg.use_init_pos || h->stepped) return KFPOS_ERR_STATE;
+    if (h->n == 3) { /* ALGORITHM_ML: the seed of every solve */
+        const int rc = stage_in(h, h->d_vel, xyz, 3, sizeof(double));
+        if (rc) return rc;
+    }
     return stage_in(h, h->d_pos, xyz, 3, sizeof(double));
 }
 
@@ -850,7 +932,10 @@ static int launch_pose(kfpos_handle *h, double dt_ahead, const double *dt_each, 
     const int blocks = (a.T + WAVE - 1) / WAVE;
     const bool f32 = h->cfg.storage == KFPOS_STORE_F32;
     hipStream_t s = (hipStream_t)stream;
-    if (h->cfg.model == KFPOS_MODEL_TOA_IMU) {
+    if (h->cfg.model == KFPOS_MODEL_ML) {
+        if (f32) hipLaunchKernelGGL((k_get_pose<3, true, float>), dim3(blocks), dim3(WAVE), 0, s, a);
+        else hipLaunchKernelGGL((k_get_pose<3, true, double>), dim3(blocks), dim3(WAVE), 0, s, a);
+    } else if (h->cfg.model == KFPOS_MODEL_TOA_IMU) {
         if (f32) hipLaunchKernelGGL((k_get_pose<9, true, float>), dim3(blocks), dim3(WAVE), 0, s, a);
         else hipLaunchKernelGGL((k_get_pose<9, true, double>), dim3(blocks), dim3(WAVE), 0, s, a);
     } else if (h->full) {

@@ -27,6 +27,7 @@ struct kfe_bank {
     std::vector<Tag9> t9;
     std::vector<Imu> imu;
     std::vector<uint32_t> flags;
+    std::vector<double> ml_pos, ml_cov, ml_seed; /* model 2: standalone ML estimator */
 };
 
 extern "C" {
@@ -50,7 +51,13 @@ kfe_bank *kfe_create(int model, int n_tags, int n_anchors, const double *anchors
     b->pr.use_init_pos = use_init_pos;
     b->flags.assign(n_tags, 0u);
     auto ip = [&](int t, int k) { return use_init_pos ? (init_pos ? init_pos[3 * t + k] : 0.0) : NAN; };
-    if (model == 0 && !b->full) {
+    if (model == 2) {
+        b->ml_pos.assign((size_t)3 * n_tags, NAN);
+        b->ml_cov.assign((size_t)6 * n_tags, NAN);
+        b->ml_seed.assign((size_t)3 * n_tags, 0.0);
+        for (int t = 0; t < n_tags; ++t)
+            for (int k = 0; k < 3; ++k) b->ml_seed[3 * t + k] = use_init_pos ? ip(t, k) : (k < 2 ? 1.0 : 4.0);
+    } else if (model == 0 && !b->full) {
         b->t6s.resize(n_tags);
         for (int t = 0; t < n_tags; ++t) {
             std::memset(&b->t6s[t], 0, sizeof(Tag6<true>));
@@ -100,6 +107,7 @@ static uint32_t step_static(kfe_bank *b, int t, const int32_t *mm, const double 
         sc.e[a] = err[a];
         sc.w[a] = 0.0;
     }
+    if (b->model == 2) return step_ml(&b->ml_pos[3 * t], &b->ml_cov[6 * t], sc, b->pr, &b->ml_seed[3 * t]);
     if (b->model == 0 && !b->full) return step_toa6(b->t6s[t], sc, b->pr, lag);
     if (b->model == 0) return step_toa6(b->t6f[t], sc, b->pr, lag);
     return step_imu9(b->t9[t], sc, b->pr, lag, true, b->imu[t]);
@@ -121,7 +129,8 @@ void kfe_step_toa(kfe_bank *b, const int32_t *range_mm, const double *err_est, c
         else if (b->use_static && b->A == 4) st = step_static<4>(b, t, mm, err, lag);
         else {
             fill_scratch(b, mm, err, buf, sc);
-            if (b->model == 0 && !b->full) st = step_toa6(b->t6s[t], sc, b->pr, lag);
+            if (b->model == 2) st = step_ml(&b->ml_pos[3 * t], &b->ml_cov[6 * t], sc, b->pr, &b->ml_seed[3 * t]);
+            else if (b->model == 0 && !b->full) st = step_toa6(b->t6s[t], sc, b->pr, lag);
             else if (b->model == 0) st = step_toa6(b->t6f[t], sc, b->pr, lag);
             else st = step_imu9(b->t9[t], sc, b->pr, lag, true, b->imu[t]);
         }
@@ -179,6 +188,15 @@ void kfe_round_storage(kfe_bank *b, int what) {
 
 /* x: T*n ([pos, vel(, 0)]), P: T*n*n full row-major */
 void kfe_get_state(const kfe_bank *b, double *x, double *P) {
+    if (b->model == 2) {
+        for (int t = 0; t < b->T; ++t) {
+            const double *c = &b->ml_cov[6 * t];
+            const double full[9] = {c[0], c[1], c[2], c[1], c[3], c[4], c[2], c[4], c[5]};
+            for (int k = 0; k < 3; ++k) x[3 * t + k] = b->ml_pos[3 * t + k];
+            for (int k = 0; k < 9; ++k) P[9 * t + k] = full[k];
+        }
+        return;
+    }
     const int n = b->model == 1 ? 9 : 6;
     for (int t = 0; t < b->T; ++t) {
         double *xt = x + (size_t)t * n, *Pt = P + (size_t)t * n * n;
