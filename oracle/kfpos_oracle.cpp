@@ -425,18 +425,34 @@ void topn_keep(const std::vector<Meas> &m, const Pos3 &seed, int topN, std::vect
 }
 
 /* ------------------------------------------------------------------ per-tag filter members */
+/* sensor_types.h:32-60: the latched samples of the other three sensors */
+struct Px4Meas { double vx, vy, gyroz, integrationTime, covVel, covGyroZ; };
+struct PlanarImuMeas { double angVelZ, covAngVelZ, ax, ay, covXY[4]; };
+struct MagMeas { double angle, cov; };
 struct Tag {
     double pos[3], vel[3];          /* mPosition.{x,y,z}, mVelocity (mAcceleration is always 0) */
     double P[81];                   /* estimationCovariance, n*n row-major */
     bool started;                   /* mLastKFTimestamp != time_point::min() */
     bool hasImu;                    /* mHasImuMeasurement */
     double imuAcc[3], imuCov[9];    /* lastImuMeasurement */
+    double ang, angSpeed;           /* KalmanFilter: mAngle, mAngularSpeed; pos[2] doubles as mUWBtagZ */
+    bool hasPx4, hasPImu, hasMag;   /* mHasPX4FlowMeasurement, mHasImuMeasurement, mHasMagMeasurement */
+    Px4Meas px4;                    /* lastPX4FlowMeasurement */
+    PlanarImuMeas pimu;             /* lastImuMeasurement */
+    MagMeas mag;                    /* lastMagMeasurement */
 };
 
 struct Params {
     int model, n, topN;
     double accelNoise, jolt, costThreshold;
     bool ignoreWorst, useFixedInit;
+    /* 8-state planar filter (KalmanFilter): <uwb useFixedHeight fixedHeight/> of config_uwb.xml, initAngle */
+    bool useFixedHeight = false;
+    double fixedHeight = 0.0, initAngle = 0.0;
+    /* config_px4flow.xml / config_imu.xml / config_mag.xml, KalmanFilter.cpp:765-842 */
+    double px4Height = 0, px4ArmP1 = 0, px4ArmP2 = 0, px4CovVel = 0, px4CovGyroZ = 0;
+    bool imuFixedCovAcc = false, imuFixedCovAngVelZ = false;
+    double imuCovAcc = 0, imuCovAngVelZ = 0, magAngleOffset = 0, magCov = 0;
 };
 
 /* predictionMatrix: KalmanFilterTOA.cpp:362-369 / KalmanFilterTOAIMU.cpp:392-402 */
@@ -755,6 +771,253 @@ unsigned imu9_estimate(const Params &pr, Tag &tg, bool hasRanging, const std::ve
     return pack_status(ns.flags, ns.gainIters, ns.mlIters, -1);
 }
 
+/* ------------------------------------------------------------------ 8-state planar filter, ranging rows */
+/* MLLocation::estimatePosition2D, MLLocation.cpp:48-143. REPAIR: `Vector3 tentativePos;` (:64) is
+ * never given a z before its distances are taken (:105-106) -- undefined behaviour in the reference; the
+ * evident intent, z = the fixed height of `position`, is what is restated. */
+bool ml_estimate_2d(const std::vector<Meas> &m, const Pos3 &seed, Pos3 &out, int *iters_out) {
+    Pos3 position = seed;
+    const int n = (int)m.size();
+    if (iters_out) *iters_out = 0;
+    if (n < 3) { out = position; return true; } /* :54-58 */
+    double cost = 1e20, newCost = 1, step = 1;
+    newCost = ml_error(m, position); /* :65 */
+    int iter = 0;
+    while ((std::fabs(cost - newCost) / cost > 1e-3) && (iter < 10000)) {
+        iter += 1;
+        cost = newCost;
+        std::vector<double> d = distances(position, m);
+        double g[2] = {0, 0};
+        Mat H2(2, 2);
+        for (int i = 0; i < n; ++i) {
+            const Meas &r = m[i];
+            const double dx = r.bx - position.x, dy = r.by - position.y;
+            g[0] += (r.ranging - d[i]) * dx / (d[i] * r.errorEstimation);
+            g[1] += (r.ranging - d[i]) * dy / (d[i] * r.errorEstimation);
+            const double d3 = d[i] * d[i] * d[i];
+            H2(0, 0) += (1 - r.ranging / d[i] + r.ranging * dx * dx / d3) / r.errorEstimation;
+            H2(1, 1) += (1 - r.ranging / d[i] + r.ranging * dy * dy / d3) / r.errorEstimation;
+            const double dxy = r.ranging * dx * dy / (d3 * r.errorEstimation);
+            H2(0, 1) += dxy;
+            H2(1, 0) += dxy;
+        }
+        std::vector<double> rhs(2), np;
+        rhs[0] = H2(0, 0) * position.x + H2(0, 1) * position.y - g[0] * step; /* :99 */
+        rhs[1] = H2(1, 0) * position.x + H2(1, 1) * position.y - g[1] * step;
+        if (!solve_equil(H2, rhs, np)) return false; /* arma::solve(A, b), :100 */
+        Pos3 tentative = position; /* REPAIR: z */
+        tentative.x = np[0];
+        tentative.y = np[1];
+        const double tentativeCost = ml_error(m, tentative);
+        if (tentativeCost > cost) {
+            step /= 2;
+        } else {
+            newCost = tentativeCost;
+            step = 1;
+            position.x = np[0];
+            position.y = np[1];
+        }
+    }
+    if (iters_out) *iters_out = iter;
+    std::vector<double> d = distances(position, m);
+    Mat J(n, 2), D(n, n), Di;
+    const double rangingError = ml_error(m, position);
+    for (int i = 0; i < n; ++i) {
+        J(i, 0) = (position.x - m[i].bx) / d[i];
+        J(i, 1) = (position.y - m[i].by) / d[i];
+        D(i, i) = stdmax(m[i].errorEstimation, rangingError); /* :136 */
+    }
+    if (!inv_lu(D, Di)) return false;
+    Mat C;
+    if (!inv_lu(mul(mul(tr(J), Di), J), C)) return false; /* :139 */
+    position.cov = C;
+    out = position;
+    return true;
+}
+
+/* predictionMatrix / predictionErrorCovariance, KalmanFilter.cpp:583-609 */
+Mat planar_F(double t) {
+    Mat F = eye(8);
+    F(0, 2) = t; F(0, 4) = t * t / 2;
+    F(1, 3) = t; F(1, 5) = t * t / 2;
+    F(2, 4) = t; F(3, 5) = t;
+    F(6, 7) = t;
+    return F;
+}
+Mat planar_Q(const Params &pr, double timeLag) {
+    const double t3 = std::pow(timeLag, 3) / 6, t2 = std::pow(timeLag, 2) / 2, t = timeLag;
+    const double a = pr.accelNoise, j = pr.jolt; /* sic: accelNoise is NOT squared here (:598, :606-607) */
+    const double u[3] = {t3, t2, t};
+    Mat Q(8, 8);
+    for (int k = 0; k < 2; ++k)
+        for (int p = 0; p < 3; ++p)
+            for (int q = 0; q < 3; ++q) Q(k + 2 * p, k + 2 * q) = j * u[std::min(p, q)] * u[std::max(p, q)];
+    Q(6, 6) = a * t2 * t2;
+    Q(6, 7) = a * t2 * t;
+    Q(7, 6) = a * t2 * t;
+    Q(7, 7) = a * t * t;
+    return Q;
+}
+double normalize_angle(double angle) { /* :699-706 */
+    if (angle > M_PI) return angle - 2 * M_PI;
+    if (angle <= -M_PI) return angle + 2 * M_PI;
+    return angle;
+}
+
+/* PX4FLOWOutput / ImuOutput and the four Jacobian blocks, KalmanFilter.cpp:558-581, 611-697 */
+struct PlanarRows { int m, nr, iPx4, iImu, iMag; };
+PlanarRows planar_rows(bool hasR, int nr, bool hasPx4, bool hasImu, bool hasMag) { /* :375-399 */
+    PlanarRows r{0, hasR ? nr : 0, 0, 0, 0};
+    r.m = r.nr;
+    if (hasPx4) { r.iPx4 = r.m; r.m += 3; }
+    if (hasImu) { r.iImu = r.m; r.m += 3; }
+    if (hasMag) { r.iMag = r.m; r.m += 1; }
+    return r;
+}
+
+/* KalmanFilter::estimatePositionKF, KalmanFilter.cpp:224-321, and kalmanStep3D, :365-501 */
+unsigned planar_estimate(const Params &pr, Tag &tg, bool hasR, const std::vector<Meas> &all, bool hasPx4,
+                         const Px4Meas &px4, bool hasImu, const PlanarImuMeas &imu, bool hasMag, const MagMeas &mag,
+                         double timeLag) {
+    tg.started = true;
+    if (!pr.useFixedInit && (std::isnan(tg.pos[0]) || std::isnan(tg.pos[1]))) { /* :243-246 */
+        if (!hasR) return 0; /* :249: only a ranging epoch can initialise */
+        Pos3 ml;
+        int it = 0;
+        if (pr.useFixedHeight) {
+            if ((int)all.size() < 3) return KFO_ST_FEW_RANGES; /* reference: empty covariance indexed -> abort */
+            if (!ml_estimate_2d(all, Pos3{1.0, 1.0, tg.pos[2], Mat()}, ml, &it)) return KFO_ST_UPDATE_SKIPPED;
+        } else {
+            if ((int)all.size() < 4) return KFO_ST_FEW_RANGES;
+            if (!ml_estimate(all, Pos3{1.0, 1.0, 4.0, Mat()}, ml, &it)) return KFO_ST_UPDATE_SKIPPED;
+            tg.pos[2] = ml.z; /* mUWBtagZ = mPosition.z, :257 */
+        }
+        tg.pos[0] = ml.x; tg.pos[1] = ml.y;
+        tg.P[0 * 8 + 0] = ml.cov(0, 0); tg.P[1 * 8 + 0] = ml.cov(1, 0);
+        tg.P[0 * 8 + 1] = ml.cov(0, 1); tg.P[1 * 8 + 1] = ml.cov(1, 1);
+        return pack_status(KFO_ST_ML_INIT, 0, it, -1);
+    }
+    const int n = 8;
+    std::vector<double> st = {tg.pos[0], tg.pos[1], tg.vel[0], tg.vel[1], 0.0, 0.0, tg.ang, tg.angSpeed};
+    const Mat F = planar_F(timeLag), Q = planar_Q(pr, timeLag);
+    std::vector<double> pred(n, 0.0);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) pred[i] += F(i, j) * st[j];
+    Mat Pm = add(mul(mul(F, P_of(tg, n)), tr(F)), Q);
+    P_to(tg, Pm);
+    pred[6] = normalize_angle(pred[6]); /* :301 */
+
+    const PlanarRows rw = planar_rows(hasR, (int)all.size(), hasPx4, hasImu, hasMag);
+    const int m = rw.m;
+    unsigned flags = 0;
+    int mlIters = 0, gains = 0;
+    std::vector<double> x(pred);
+    Mat R = eye(m);
+    std::vector<double> z(m, 0.0);
+    if (hasR) { /* :403-411 */
+        Pos3 ml;
+        if (!ml_estimate_2d(all, Pos3{x[0], x[1], tg.pos[2], Mat()}, ml, &mlIters)) return KFO_ST_UPDATE_SKIPPED;
+        if (rw.nr < 3) flags |= KFO_ST_FEW_RANGES;
+        const double e_ml = ml_error(all, ml);
+        for (int i = 0; i < rw.nr; ++i) {
+            z[i] = all[i].ranging;
+            R(i, i) = stdmax(e_ml, all[i].errorEstimation);
+        }
+    }
+    if (hasPx4) { /* :413-424 */
+        z[rw.iPx4] = px4.vx; z[rw.iPx4 + 1] = px4.vy; z[rw.iPx4 + 2] = px4.gyroz;
+        R(rw.iPx4, rw.iPx4) = px4.covVel;
+        R(rw.iPx4 + 1, rw.iPx4 + 1) = px4.covVel;
+        R(rw.iPx4 + 2, rw.iPx4 + 2) = px4.covGyroZ;
+    }
+    if (hasImu) { /* :426-436 */
+        z[rw.iImu] = imu.ax; z[rw.iImu + 1] = imu.ay; z[rw.iImu + 2] = imu.angVelZ;
+        R(rw.iImu, rw.iImu) = imu.covXY[0];
+        R(rw.iImu, rw.iImu + 1) = imu.covXY[1];
+        R(rw.iImu + 1, rw.iImu) = imu.covXY[2];
+        R(rw.iImu + 1, rw.iImu + 1) = imu.covXY[3];
+        R(rw.iImu + 2, rw.iImu + 2) = imu.covAngVelZ;
+    }
+    if (hasMag) { /* :438-442 */
+        z[rw.iMag] = mag.angle;
+        R(rw.iMag, rw.iMag) = mag.cov;
+    }
+    Mat H(m, n), K(n, m), Ri, Pp;
+    if (!inv_lu(R, Ri)) return KFO_ST_UPDATE_SKIPPED;
+    if (!pinv_svd(Pm, Pp)) return KFO_ST_UPDATE_SKIPPED;
+    double cost = 1e20;
+    for (int iter = 0; iter < 20; ++iter) {
+        Pos3 cur{x[0], x[1], tg.pos[2], Mat()};
+        const double vx = x[2], vy = x[3], ax = x[4], ay = x[5], th = x[6], om = x[7];
+        std::vector<double> d = hasR ? distances(cur, all) : std::vector<double>();
+        Mat y(m, 1), dlt(n, 1);
+        for (int i = 0; i < rw.nr; ++i) y(i, 0) = z[i] - d[i];
+        if (hasPx4) { /* px4flowOutput, :558-566 */
+            const double p1 = pr.px4ArmP1, p2 = pr.px4ArmP2;
+            const double ox = std::cos(th) * vx + std::sin(th) * vy +
+                              1 / timeLag * ((1 - std::cos(om * timeLag)) * p1 - std::sin(om * timeLag) * p2);
+            const double oy = -std::sin(th) * vx + std::cos(th) * vy +
+                              1 / timeLag * (std::sin(om * timeLag) * p1 + (1 - std::cos(om * timeLag)) * p2);
+            y(rw.iPx4, 0) = z[rw.iPx4] - ox;
+            y(rw.iPx4 + 1, 0) = z[rw.iPx4 + 1] - oy;
+            y(rw.iPx4 + 2, 0) = z[rw.iPx4 + 2] - om;
+        }
+        if (hasImu) { /* imuOutput, :568-576 */
+            y(rw.iImu, 0) = z[rw.iImu] - (std::cos(th) * ax + std::sin(th) * ay);
+            y(rw.iImu + 1, 0) = z[rw.iImu + 1] - (-std::sin(th) * ax + std::cos(th) * ay);
+            y(rw.iImu + 2, 0) = z[rw.iImu + 2] - om;
+        }
+        if (hasMag) y(rw.iMag, 0) = normalize_angle(z[rw.iMag] - th); /* :460-462 */
+        for (int i = 0; i < n; ++i) dlt(i, 0) = pred[i] - x[i];
+        const double newCost = add(mul(mul(tr(y), Ri), y), mul(mul(tr(dlt), Pp), dlt))(0, 0);
+        if (std::fabs(cost - newCost) / cost < 1e-4) break;
+        cost = newCost;
+        /* `jacobian` is allocated uninitialised once (:444) and every block writes all 8 columns of its rows */
+        for (int i = 0; i < rw.nr; ++i) { /* jacobianRangings, :611-625 */
+            for (int c = 0; c < n; ++c) H(i, c) = 0;
+            H(i, 0) = (cur.x - all[i].bx) / d[i];
+            H(i, 1) = (cur.y - all[i].by) / d[i];
+        }
+        if (hasPx4) { /* jacobianPx4flow, :627-655 */
+            const int r0 = rw.iPx4;
+            for (int k = 0; k < 3; ++k)
+                for (int c = 0; c < n; ++c) H(r0 + k, c) = 0;
+            H(r0, 2) = std::cos(th); H(r0, 3) = std::sin(th);
+            H(r0, 6) = -std::sin(th) * vx + std::cos(th) * vy;
+            H(r0, 7) = pr.px4ArmP1 * std::sin(om * timeLag) - pr.px4ArmP2 * std::cos(om * timeLag);
+            H(r0 + 1, 2) = -std::sin(th); H(r0 + 1, 3) = std::cos(th);
+            H(r0 + 1, 6) = -std::cos(th) * vx - std::sin(th) * vy;
+            H(r0 + 1, 7) = pr.px4ArmP1 * std::cos(om * timeLag) + pr.px4ArmP2 * std::sin(om * timeLag);
+            H(r0 + 2, 7) = 1;
+        }
+        if (hasImu) { /* jacobianImu, :657-686 */
+            const int r0 = rw.iImu;
+            for (int k = 0; k < 3; ++k)
+                for (int c = 0; c < n; ++c) H(r0 + k, c) = 0;
+            H(r0, 4) = std::cos(th); H(r0, 5) = std::sin(th);
+            H(r0, 6) = -std::sin(th) * ax + std::cos(th) * ay;
+            H(r0 + 1, 4) = -std::sin(th); H(r0 + 1, 5) = std::cos(th);
+            H(r0 + 1, 6) = -std::cos(th) * ax - std::sin(th) * ay;
+            H(r0 + 2, 7) = 1;
+        }
+        if (hasMag) { /* jacobianMag, :688-697 */
+            for (int c = 0; c < n; ++c) H(rw.iMag, c) = 0;
+            H(rw.iMag, 6) = 1;
+        }
+        Mat S = add(mul(mul(H, Pm), tr(H)), R), Si;
+        if (!inv_lu(S, Si)) return KFO_ST_UPDATE_SKIPPED;
+        K = mul(mul(Pm, tr(H)), Si);
+        Mat dir = add(dlt, mul(K, sub(y, mul(H, dlt))));
+        for (int i = 0; i < n; ++i) x[i] += dir(i, 0);
+        gains++;
+    }
+    P_to(tg, mul(sub(eye(n), mul(K, H)), Pm));
+    tg.pos[0] = x[0]; tg.pos[1] = x[1];
+    tg.vel[0] = x[2]; tg.vel[1] = x[3];
+    tg.ang = x[6]; tg.angSpeed = x[7]; /* :316-319; the acceleration state is not kept */
+    return pack_status(flags, gains, mlIters, -1);
+}
+
 } // namespace
 
 /* ------------------------------------------------------------------ C interface */
@@ -800,6 +1063,26 @@ unsigned finite_flag(const Tag &tg, int n) {
 }
 } // namespace
 
+
+namespace {
+template <class Fn> void planar_each(kfo_filter_bank *o, const double *dt, int dt_len, uint32_t *status, int n_threads, Fn fn) {
+    parallel_tags(o->T, n_threads, [=](int lo, int hi) {
+        for (int t = lo; t < hi; ++t) {
+            Tag &tg = o->tags[t];
+            const double lag = dt[dt_len > 1 ? t : 0];
+            if (dt_len > 1 && lag < 0) {
+                if (status) status[t] = KFO_ST_SKIPPED;
+                continue;
+            }
+            unsigned st = fn(t, tg, lag);
+            const bool uninit = !o->pr.useFixedInit && std::isnan(tg.pos[0]);
+            if (!uninit && !(st & KFO_ST_SKIPPED)) st |= finite_flag(tg, 8);
+            if (status) status[t] = st;
+        }
+    });
+}
+} // namespace
+
 extern "C" {
 
 kfo_filter_bank *kfo_create(int model, int n_tags, int max_anchors, double accel_noise, double jolt,
@@ -807,7 +1090,7 @@ kfo_filter_bank *kfo_create(int model, int n_tags, int max_anchors, double accel
                             const double *init_pos) {
     kfo_filter_bank *o = new kfo_filter_bank();
     o->pr.model = model;
-    o->pr.n = (model == KFO_MODEL_TOA_IMU) ? 9 : (model == KFO_MODEL_ML ? 3 : 6);
+    o->pr.n = (model == KFO_MODEL_TOA_IMU) ? 9 : (model == KFO_MODEL_ML ? 3 : (model == KFO_MODEL_PLANAR ? 8 : 6));
     o->pr.topN = top_n;
     o->pr.accelNoise = accel_noise;
     o->pr.jolt = jolt;
@@ -830,6 +1113,25 @@ kfo_filter_bank *kfo_create(int model, int n_tags, int max_anchors, double accel
     return o;
 }
 void kfo_destroy(kfo_filter_bank *o) { delete o; }
+void kfo_set_planar(kfo_filter_bank *o, const kfo_planar_config *c) {
+    Params &p = o->pr;
+    p.useFixedHeight = c->use_fixed_height != 0;
+    p.fixedHeight = c->fixed_height;
+    p.initAngle = c->init_angle;
+    p.px4Height = c->px4_height; p.px4ArmP1 = c->px4_arm_p1; p.px4ArmP2 = c->px4_arm_p2;
+    p.px4CovVel = c->px4_cov_velocity; p.px4CovGyroZ = c->px4_cov_gyro_z;
+    p.imuFixedCovAcc = c->imu_use_fixed_cov_acc != 0; p.imuCovAcc = c->imu_cov_acc;
+    p.imuFixedCovAngVelZ = c->imu_use_fixed_cov_ang_vel_z != 0; p.imuCovAngVelZ = c->imu_cov_ang_vel_z;
+    p.magAngleOffset = c->mag_angle_offset; p.magCov = c->mag_cov;
+    for (Tag &tg : o->tags) {
+        tg.pos[2] = c->fixed_height; /* mUWBtagZ, KalmanFilter.cpp:797; the z of an initial position is not used */
+        tg.ang = c->init_angle;
+        tg.angSpeed = 0.0;
+    }
+}
+void kfo_get_height(const kfo_filter_bank *o, double *z) {
+    for (int t = 0; t < o->T; ++t) z[t] = o->tags[t].pos[2];
+}
 int kfo_state_dim(const kfo_filter_bank *o) { return o->pr.n; }
 void kfo_set_anchors(kfo_filter_bank *o, const double *xyz, int n_anchors) {
     o->A = n_anchors;
@@ -850,6 +1152,14 @@ void kfo_step_toa(kfo_filter_bank *o, const int32_t *range_mm, const double *err
             if (o->pr.model == KFO_MODEL_ML) {
                 const double one14[3] = {1.0, 1.0, 4.0};
                 const unsigned st = ml_estimator(o->pr, tg, m, o->pr.useFixedInit ? &o->ml_seed[3 * (size_t)t] : one14);
+                if (status) status[t] = st;
+                continue;
+            }
+            if (o->pr.model == KFO_MODEL_PLANAR) {
+                /* newTOAMeasurement, KalmanFilter.cpp:66-99: the three latched samples ride along */
+                unsigned st = planar_estimate(o->pr, tg, true, m, tg.hasPx4, tg.px4, tg.hasPImu, tg.pimu, tg.hasMag, tg.mag, lag);
+                const bool uninit = !o->pr.useFixedInit && std::isnan(tg.pos[0]);
+                if (!uninit) st |= finite_flag(tg, 8);
                 if (status) status[t] = st;
                 continue;
             }
@@ -884,11 +1194,77 @@ void kfo_step_imu(kfo_filter_bank *o, const double *accel, const double *cov, co
     });
 }
 
+/* KalmanFilter::newPX4FlowMeasurement, KalmanFilter.cpp:102-135. flow: T x 5 = integrationX, integrationY,
+ * integrationRotationZ, integrationTime [us], quality. */
+void kfo_planar_px4flow(kfo_filter_bank *o, const double *flow, const double *dt, int dt_len, uint32_t *status, int n_threads) {
+    planar_each(o, dt, dt_len, status, n_threads, [=](int t, Tag &tg, double lag) -> unsigned {
+        const double *f = flow + 5 * (size_t)t;
+        const Params &pr = o->pr;
+        const int quality = (int)f[4];
+        Px4Meas m;
+        m.vy = f[1] / (f[3] / 1000000.0) * pr.px4Height;
+        m.vx = f[0] / (f[3] / 1000000.0) * pr.px4Height;
+        m.gyroz = f[2] / (f[3] / 1000000.0);
+        m.integrationTime = f[3] / 1000000.0;
+        if (quality == 0) return KFO_ST_SKIPPED; /* :113-115: nothing latched, no estimate, no timestamp */
+        if (f[3] > 0) m.covVel = pr.px4CovVel / m.integrationTime * pr.px4Height / quality;
+        else m.covVel = pr.px4CovVel * quality;
+        m.covGyroZ = pr.px4CovGyroZ;
+        tg.px4 = m;
+        tg.hasPx4 = true;
+        return planar_estimate(pr, tg, false, std::vector<Meas>(), true, m, false, PlanarImuMeas(), false, MagMeas(), lag);
+    });
+}
+/* KalmanFilter::newIMUMeasurement, KalmanFilter.cpp:139-182 */
+void kfo_planar_imu(kfo_filter_bank *o, const double *ang_vel, const double *cov_ang_vel, const double *lin_acc,
+                    const double *cov_acc, const double *dt, int dt_len, uint32_t *status, int n_threads) {
+    planar_each(o, dt, dt_len, status, n_threads, [=](int t, Tag &tg, double lag) -> unsigned {
+        const Params &pr = o->pr;
+        const double *ca = cov_acc + 9 * (size_t)t;
+        PlanarImuMeas m;
+        m.covXY[0] = pr.imuFixedCovAcc ? pr.imuCovAcc : ca[0];
+        m.covXY[1] = ca[1];
+        m.covXY[2] = ca[3];
+        m.covXY[3] = pr.imuFixedCovAcc ? pr.imuCovAcc : ca[4];
+        m.covAngVelZ = pr.imuFixedCovAngVelZ ? pr.imuCovAngVelZ : cov_ang_vel[9 * (size_t)t + 8];
+        m.angVelZ = ang_vel[3 * (size_t)t + 2];
+        m.ax = lin_acc[3 * (size_t)t];
+        m.ay = lin_acc[3 * (size_t)t + 1];
+        tg.pimu = m;
+        tg.hasPImu = true;
+        return planar_estimate(pr, tg, false, std::vector<Meas>(), false, Px4Meas(), true, m, false, MagMeas(), lag);
+    });
+}
+/* KalmanFilter::newMAGMeasurement, KalmanFilter.cpp:185-199 (the covarianceMag argument is ignored there) */
+void kfo_planar_mag(kfo_filter_bank *o, const double *mag_xyz, const double *dt, int dt_len, uint32_t *status, int n_threads) {
+    planar_each(o, dt, dt_len, status, n_threads, [=](int t, Tag &tg, double lag) -> unsigned {
+        MagMeas m;
+        m.angle = std::atan2(mag_xyz[3 * (size_t)t + 1], mag_xyz[3 * (size_t)t]) - o->pr.magAngleOffset;
+        m.cov = o->pr.magCov;
+        tg.mag = m;
+        tg.hasMag = true;
+        return planar_estimate(o->pr, tg, false, std::vector<Meas>(), false, Px4Meas(), false, PlanarImuMeas(), true, m, lag);
+    });
+}
+/* KalmanFilter::newCompassMeasurement, KalmanFilter.cpp:201-229: the latched PX4Flow and IMU samples ride along */
+void kfo_planar_compass(kfo_filter_bank *o, const double *compass, const double *dt, int dt_len, uint32_t *status, int n_threads) {
+    planar_each(o, dt, dt_len, status, n_threads, [=](int t, Tag &tg, double lag) -> unsigned {
+        MagMeas m;
+        m.angle = normalize_angle(compass[t]);
+        m.cov = o->pr.magCov;
+        tg.mag = m;
+        tg.hasMag = true;
+        return planar_estimate(o->pr, tg, false, std::vector<Meas>(), tg.hasPx4, tg.px4, tg.hasPImu, tg.pimu, true, m, lag);
+    });
+}
+
 void kfo_get_pose(const kfo_filter_bank *o, double dt_ahead, double *pos, double *cov3x3, double *vel,
                   uint32_t *status) {
     const int n = o->pr.n;
     const bool is_ml = o->pr.model == KFO_MODEL_ML;
-    const Mat F = is_ml ? Mat() : pred_F(n, dt_ahead), Q = is_ml ? Mat() : pred_Q(o->pr, dt_ahead);
+    const bool is_planar = o->pr.model == KFO_MODEL_PLANAR;
+    const Mat F = is_ml ? Mat() : (is_planar ? planar_F(dt_ahead) : pred_F(n, dt_ahead)),
+              Q = is_ml ? Mat() : (is_planar ? planar_Q(o->pr, dt_ahead) : pred_Q(o->pr, dt_ahead));
     for (int t = 0; t < o->T; ++t) {
         const Tag &tg = o->tags[t];
         if (!tg.started) { /* getPose returns false: pose untouched = NaN (Posgenerator.cpp:542) */
@@ -904,10 +1280,20 @@ void kfo_get_pose(const kfo_filter_bank *o, double dt_ahead, double *pos, double
             continue;
         }
         std::vector<double> st(n, 0.0), pred(n, 0.0);
-        for (int k = 0; k < 3; ++k) { st[k] = tg.pos[k]; if (n == 9) st[3 + k] = tg.vel[k]; }
+        if (is_planar) st = {tg.pos[0], tg.pos[1], tg.vel[0], tg.vel[1], 0.0, 0.0, tg.ang, tg.angSpeed};
+        else
+            for (int k = 0; k < 3; ++k) { st[k] = tg.pos[k]; if (n == 9) st[3 + k] = tg.vel[k]; }
         for (int i = 0; i < n; ++i)
             for (int j = 0; j < n; ++j) pred[i] += F(i, j) * st[j];
         Mat Pp = add(mul(mul(F, P_of(tg, n)), tr(F)), Q);
+        if (is_planar) { /* KalmanFilter::getPose + stateToPose, KalmanFilter.cpp:709-745, 324-363: position block of the 6x6 */
+            pos[3 * t] = pred[0]; pos[3 * t + 1] = pred[1]; pos[3 * t + 2] = tg.pos[2];
+            if (vel) { vel[3 * t] = pred[2]; vel[3 * t + 1] = pred[3]; vel[3 * t + 2] = 0.0; }
+            const double c[9] = {Pp(0, 0), Pp(0, 1), 0, Pp(1, 0), Pp(1, 1), 0, 0, 0, 0.01};
+            std::memcpy(cov3x3 + 9 * t, c, sizeof(c));
+            if (status) status[t] = 0;
+            continue;
+        }
         for (int k = 0; k < 3; ++k) {
             pos[3 * t + k] = pred[k];
             if (vel) vel[3 * t + k] = pred[3 + k];
@@ -922,7 +1308,11 @@ void kfo_get_state(const kfo_filter_bank *o, double *x, double *P) {
     for (int t = 0; t < o->T; ++t) {
         const Tag &tg = o->tags[t];
         for (int k = 0; k < n; ++k) x[(size_t)t * n + k] = 0.0;
-        for (int k = 0; k < 3; ++k) { x[(size_t)t * n + k] = tg.pos[k]; if (n == 9) x[(size_t)t * n + 3 + k] = tg.vel[k]; }
+        if (o->pr.model == KFO_MODEL_PLANAR) {
+            const double s8[8] = {tg.pos[0], tg.pos[1], tg.vel[0], tg.vel[1], 0.0, 0.0, tg.ang, tg.angSpeed};
+            std::memcpy(x + (size_t)t * 8, s8, sizeof(s8));
+        } else
+            for (int k = 0; k < 3; ++k) { x[(size_t)t * n + k] = tg.pos[k]; if (n == 9) x[(size_t)t * n + 3 + k] = tg.vel[k]; }
         std::memcpy(P + (size_t)t * n * n, tg.P, sizeof(double) * n * n);
     }
 }
@@ -930,7 +1320,11 @@ void kfo_set_state(kfo_filter_bank *o, const double *x, const double *P, int sta
     const int n = o->pr.n;
     for (int t = 0; t < o->T; ++t) {
         Tag &tg = o->tags[t];
-        for (int k = 0; k < 3; ++k) { tg.pos[k] = x[(size_t)t * n + k]; tg.vel[k] = (n == 9) ? x[(size_t)t * n + 3 + k] : 0.0; }
+        if (o->pr.model == KFO_MODEL_PLANAR) { /* the height (pos[2]) is kept */
+            const double *s8 = x + (size_t)t * 8;
+            tg.pos[0] = s8[0]; tg.pos[1] = s8[1]; tg.vel[0] = s8[2]; tg.vel[1] = s8[3]; tg.ang = s8[6]; tg.angSpeed = s8[7];
+        } else
+            for (int k = 0; k < 3; ++k) { tg.pos[k] = x[(size_t)t * n + k]; tg.vel[k] = (n == 9) ? x[(size_t)t * n + 3 + k] : 0.0; }
         std::memcpy(tg.P, P + (size_t)t * n * n, sizeof(double) * n * n);
         tg.started = started != 0;
     }

@@ -28,6 +28,7 @@ typedef struct kfo_filter_bank kfo_filter_bank;
 #define KFO_MODEL_TOA     0 /* KalmanFilterTOA,    6 states */
 #define KFO_MODEL_TOA_IMU 1 /* KalmanFilterTOAIMU, 9 states (with the 3-token repair) */
 #define KFO_MODEL_ML      2 /* MLLocation as a standalone estimator (ALGORITHM_ML), 3-D, variant NORMAL / IGNORE_N */
+#define KFO_MODEL_PLANAR  3 /* KalmanFilter (ALGORITHM_KF), 8 states [x y vx vy ax ay theta omega], ranging rows */
 
 /* per-tag status bits reported by a step (same layout as include/kfpos.h) */
 #define KFO_ST_UPDATE_SKIPPED 0x01u /* inv/pinv/solve "threw": predicted P kept (KalmanFilterTOA.cpp:151-153) */
@@ -47,6 +48,26 @@ kfo_filter_bank *kfo_create(int model, int n_tags, int max_anchors,
                             int use_init_pos, const double *init_pos /* n_tags*3 or NULL */);
 void kfo_destroy(kfo_filter_bank *);
 int  kfo_state_dim(const kfo_filter_bank *);
+/* KFO_MODEL_PLANAR: what KalmanFilter::loadConfigurationFiles reads (KalmanFilter.cpp:748-842) plus the
+ * constructor's initialAngle; call before the first step. kfo_get_height returns mUWBtagZ per tag. */
+typedef struct {
+    int use_fixed_height; double fixed_height; /* <uwb useFixedHeight fixedHeight/> */
+    double init_angle;
+    double px4_height, px4_arm_p1, px4_arm_p2, px4_cov_velocity, px4_cov_gyro_z; /* <px4flow sensorHeight armP0 armP1 .../> */
+    int imu_use_fixed_cov_acc; double imu_cov_acc;                               /* <imu .../> */
+    int imu_use_fixed_cov_ang_vel_z; double imu_cov_ang_vel_z;
+    double mag_angle_offset, mag_cov;                                            /* <mag angleOffset covarianceMag/> */
+} kfo_planar_config;
+void kfo_set_planar(kfo_filter_bank *, const kfo_planar_config *);
+void kfo_get_height(const kfo_filter_bank *, double *z);
+/* The other four sensor entry points of KalmanFilter (dt as in kfo_step_toa; dt < 0 with dt_len = n_tags skips a tag).
+ * flow: T x 5 (integrationX, integrationY, integrationRotationZ, integrationTime [us], quality); a sample with
+ * quality 0 is dropped exactly like the reference does (status KFO_ST_SKIPPED). */
+void kfo_planar_px4flow(kfo_filter_bank *, const double *flow, const double *dt, int dt_len, uint32_t *status, int n_threads);
+void kfo_planar_imu(kfo_filter_bank *, const double *ang_vel, const double *cov_ang_vel, const double *lin_acc,
+                    const double *cov_acc, const double *dt, int dt_len, uint32_t *status, int n_threads);
+void kfo_planar_mag(kfo_filter_bank *, const double *mag_xyz, const double *dt, int dt_len, uint32_t *status, int n_threads);
+void kfo_planar_compass(kfo_filter_bank *, const double *compass, const double *dt, int dt_len, uint32_t *status, int n_threads);
 void kfo_set_anchors(kfo_filter_bank *, const double *xyz /* A*3 */, int n_anchors);
 
 /* One ranging epoch for every tag: KalmanFilterTOA::newTOAMeasurement

@@ -258,3 +258,230 @@ class NumpyFilter:
         st = np.concatenate([self.pos, self.vel if self.n == 9 else np.zeros(3), np.zeros(self.n - 6)])
         Pp = F @ self.P @ F.T + Q
         return (F @ st)[:3], Pp[:3, :3]
+
+
+# ---------------------------------------------------------------------------------------------------
+# 8-state planar filter (KalmanFilter, ALGORITHM_KF): KalmanFilter.cpp:66-229, 224-321, 365-501, 558-745;
+# MLLocation::estimatePosition2D, MLLocation.cpp:48-143 (with the tentative-z repair of DESIGN.md).
+# ---------------------------------------------------------------------------------------------------
+def arma_solve(A, b):
+    """arma::solve(A, b) with default options: LU, and an approximate (SVD) solution when rcond is tiny."""
+    if not (np.all(np.isfinite(A)) and np.all(np.isfinite(b))):
+        return np.full_like(b, np.nan)
+    try:
+        if np.linalg.cond(A, 1) * EPS > 1.0:
+            return arma_pinv(A) @ b
+        return np.linalg.solve(A, b)
+    except np.linalg.LinAlgError:
+        return arma_pinv(A) @ b
+
+
+def ml_estimate_2d(meas, seed):
+    p = np.array(seed, dtype=np.float64)
+    n = len(meas)
+    if n < 3:
+        return p, None, 0
+    cost, new_cost, step, it = np.float64(1e20), np.float64(ml_error(meas, p)), 1.0, 0
+    with np.errstate(all="ignore"):
+        while abs(cost - new_cost) / cost > 1e-3 and it < 10000:
+            it += 1
+            cost = new_cost
+            d = distances(p, meas)
+            g, Hs = np.zeros(2), np.zeros((2, 2))
+            for i, (r, e, bx, by, _) in enumerate(meas):
+                v = np.array([bx - p[0], by - p[1]])
+                g += (r - d[i]) * v / (d[i] * e)
+                d3 = d[i] * d[i] * d[i]
+                Hs[0, 0] += (1 - r / d[i] + r * v[0] * v[0] / d3) / e
+                Hs[1, 1] += (1 - r / d[i] + r * v[1] * v[1] / d3) / e
+                t = r * v[0] * v[1] / (d3 * e)
+                Hs[0, 1] += t
+                Hs[1, 0] += t
+            q = arma_solve(Hs, Hs @ p[:2] - g * step)
+            tent = np.array([q[0], q[1], p[2]])
+            tent_cost = np.float64(ml_error(meas, tent))
+            if tent_cost > cost:
+                step /= 2
+            else:
+                new_cost, step, p = tent_cost, 1.0, tent
+        d = distances(p, meas)
+        rng_err = ml_error(meas, p)
+        J = np.array([[(p[0] - m[2]) / d[i], (p[1] - m[3]) / d[i]] for i, m in enumerate(meas)])
+        obs = np.array([_stdmax(m[1], rng_err) for m in meas])
+        C = arma_inv(J.T @ arma_inv(np.diag(obs)) @ J)
+    return p, C, it
+
+
+def planar_F(t):
+    F = np.eye(8)
+    F[0, 2] = F[1, 3] = F[2, 4] = F[3, 5] = F[6, 7] = t
+    F[0, 4] = F[1, 5] = t * t / 2
+    return F
+
+
+def planar_Q(t, accel_noise, jolt):
+    u = [t ** 3 / 6, t ** 2 / 2, t]
+    Q = np.zeros((8, 8))
+    for k in range(2):
+        for a in range(3):
+            for b in range(3):
+                Q[k + 2 * a, k + 2 * b] = jolt * u[min(a, b)] * u[max(a, b)]
+    Q[6, 6], Q[6, 7], Q[7, 6], Q[7, 7] = accel_noise * u[1] * u[1], accel_noise * u[1] * t, accel_noise * u[1] * t, accel_noise * t * t
+    return Q
+
+
+def normalize_angle(a):
+    if a > np.pi:
+        return a - 2 * np.pi
+    if a <= -np.pi:
+        return a + 2 * np.pi
+    return a
+
+
+class NumpyPlanarFilter:
+    """One KalmanFilter (8 states). cfg keys as oracle_py.PlanarConfig."""
+
+    def __init__(self, anchors, accel_noise=0.5, jolt=0.5, init_pos=None, **cfg):
+        self.anchors = np.asarray(anchors, dtype=np.float64)
+        self.accel_noise, self.jolt = accel_noise, jolt
+        self.c = dict(use_fixed_height=0, fixed_height=0.0, init_angle=0.0, px4_height=0.0, px4_arm_p1=0.0,
+                      px4_arm_p2=0.0, px4_cov_velocity=0.0, px4_cov_gyro_z=0.0, imu_use_fixed_cov_acc=0,
+                      imu_cov_acc=0.0, imu_use_fixed_cov_ang_vel_z=0, imu_cov_ang_vel_z=0.0, mag_angle_offset=0.0,
+                      mag_cov=0.0)
+        self.c.update(cfg)
+        self.fixed = init_pos is not None
+        self.xy = np.array(init_pos[:2], dtype=np.float64) if self.fixed else np.full(2, np.nan)
+        self.z = float(self.c["fixed_height"])
+        self.vel = np.zeros(2)
+        self.ang, self.ang_speed = float(self.c["init_angle"]), 0.0
+        self.P = np.zeros((8, 8))
+        self.px4 = self.imu = self.mag = None
+
+    def _meas(self, range_mm, err_est):
+        return [(float(mm) / 1000, float(e), *self.anchors[a]) for a, (mm, e) in
+                enumerate(zip(range_mm, err_est)) if mm > 0]
+
+    def step_toa(self, range_mm, err_est, dt):
+        self._estimate(self._meas(range_mm, err_est), self.px4, self.imu, self.mag, dt, True)
+
+    def step_px4flow(self, ix, iy, irz, itime_us, quality, dt):
+        c, quality = self.c, int(quality)
+        with np.errstate(all="ignore"):
+            tsec = np.float64(itime_us) / 1000000.0
+            vx, vy, gz = ix / tsec * c["px4_height"], iy / tsec * c["px4_height"], irz / tsec
+            if quality == 0:
+                return
+            cv = c["px4_cov_velocity"] / tsec * c["px4_height"] / quality if itime_us > 0 else c["px4_cov_velocity"] * quality
+        self.px4 = (vx, vy, gz, cv, c["px4_cov_gyro_z"])
+        self._estimate(None, self.px4, None, None, dt, False)
+
+    def step_imu(self, ang_vel, cov_ang_vel, lin_acc, cov_acc, dt):
+        c, ca = self.c, np.asarray(cov_acc, dtype=np.float64).ravel()
+        cxy = np.array([[c["imu_cov_acc"] if c["imu_use_fixed_cov_acc"] else ca[0], ca[1]],
+                        [ca[3], c["imu_cov_acc"] if c["imu_use_fixed_cov_acc"] else ca[4]]])
+        cw = c["imu_cov_ang_vel_z"] if c["imu_use_fixed_cov_ang_vel_z"] else np.asarray(cov_ang_vel).ravel()[8]
+        self.imu = (lin_acc[0], lin_acc[1], ang_vel[2], cxy, cw)
+        self._estimate(None, None, self.imu, None, dt, False)
+
+    def step_mag(self, mag_xyz, dt):
+        self.mag = (np.arctan2(mag_xyz[1], mag_xyz[0]) - self.c["mag_angle_offset"], self.c["mag_cov"])
+        self._estimate(None, None, None, self.mag, dt, False)
+
+    def step_compass(self, compass, dt):
+        self.mag = (normalize_angle(compass), self.c["mag_cov"])
+        self._estimate(None, self.px4, self.imu, self.mag, dt, False)
+
+    def _estimate(self, meas, px4, imu, mag, dt, has_r):
+        if not self.fixed and np.any(np.isnan(self.xy)):
+            if has_r:
+                if self.c["use_fixed_height"]:
+                    if len(meas) < 3:
+                        return
+                    p, C, _ = ml_estimate_2d(meas, [1.0, 1.0, self.z])
+                else:
+                    if len(meas) < 4:
+                        return
+                    p, C, _ = ml_estimate(meas, [1.0, 1.0, 4.0])
+                    self.z = p[2]
+                self.xy = p[:2].copy()
+                self.P[:2, :2] = C[:2, :2]
+            return
+        F, Q = planar_F(dt), planar_Q(dt, self.accel_noise, self.jolt)
+        pred = F @ np.array([self.xy[0], self.xy[1], self.vel[0], self.vel[1], 0.0, 0.0, self.ang, self.ang_speed])
+        self.P = F @ self.P @ F.T + Q
+        pred[6] = normalize_angle(pred[6])
+        try:
+            x, Pn = self._kalman_step(pred, self.P, meas if has_r else [], px4, imu, mag, dt)
+        except LinAlgThrow:
+            return
+        self.P, self.xy, self.vel, self.ang, self.ang_speed = Pn, x[:2].copy(), x[2:4].copy(), x[6], x[7]
+
+    def _kalman_step(self, pred, Pm, rm, px4, imu, mag, t):
+        nr = len(rm)
+        i_px4 = nr
+        i_imu = i_px4 + (3 if px4 else 0)
+        i_mag = i_imu + (3 if imu else 0)
+        m = i_mag + (1 if mag else 0)
+        R, zz = np.eye(m), np.zeros(m)
+        x = np.array(pred, dtype=np.float64)
+        p1, p2 = self.c["px4_arm_p1"], self.c["px4_arm_p2"]
+        with np.errstate(all="ignore"):
+            if nr > 0:
+                ml, _, _ = ml_estimate_2d(rm, [x[0], x[1], self.z])
+                e_ml = ml_error(rm, ml)
+                for i, mm in enumerate(rm):
+                    zz[i], R[i, i] = mm[0], _stdmax(e_ml, mm[1])
+            if px4:
+                zz[i_px4:i_px4 + 3] = px4[:3]
+                R[i_px4, i_px4] = R[i_px4 + 1, i_px4 + 1] = px4[3]
+                R[i_px4 + 2, i_px4 + 2] = px4[4]
+            if imu:
+                zz[i_imu:i_imu + 3] = imu[:3]
+                R[i_imu:i_imu + 2, i_imu:i_imu + 2] = imu[3]
+                R[i_imu + 2, i_imu + 2] = imu[4]
+            if mag:
+                zz[i_mag], R[i_mag, i_mag] = mag
+            Ri, Pp = arma_inv(R), arma_pinv(Pm)
+            H, K = np.zeros((m, 8)), np.zeros((8, m))
+            cost = np.float64(1e20)
+            for _ in range(20):
+                vx, vy, ax, ay, th, om = x[2:8]
+                h = np.zeros(m)
+                d = distances([x[0], x[1], self.z], rm)
+                h[:nr] = d
+                c_, s_ = np.cos(th), np.sin(th)
+                if px4:
+                    h[i_px4] = c_ * vx + s_ * vy + 1 / t * ((1 - np.cos(om * t)) * p1 - np.sin(om * t) * p2)
+                    h[i_px4 + 1] = -s_ * vx + c_ * vy + 1 / t * (np.sin(om * t) * p1 + (1 - np.cos(om * t)) * p2)
+                    h[i_px4 + 2] = om
+                if imu:
+                    h[i_imu:i_imu + 3] = [c_ * ax + s_ * ay, -s_ * ax + c_ * ay, om]
+                if mag:
+                    h[i_mag] = th
+                y, dl = zz - h, pred - x
+                if mag:
+                    y[i_mag] = normalize_angle(y[i_mag])
+                new_cost = np.float64(y @ Ri @ y + dl @ Pp @ dl)
+                if abs(cost - new_cost) / cost < 1e-4:
+                    break
+                cost = new_cost
+                H[:] = 0.0
+                for i, mm in enumerate(rm):
+                    H[i, 0], H[i, 1] = (x[0] - mm[2]) / d[i], (x[1] - mm[3]) / d[i]
+                if px4:
+                    H[i_px4, [2, 3, 6, 7]] = [c_, s_, -s_ * vx + c_ * vy, p1 * np.sin(om * t) - p2 * np.cos(om * t)]
+                    H[i_px4 + 1, [2, 3, 6, 7]] = [-s_, c_, -c_ * vx - s_ * vy, p1 * np.cos(om * t) + p2 * np.sin(om * t)]
+                    H[i_px4 + 2, 7] = 1
+                if imu:
+                    H[i_imu, [4, 5, 6]] = [c_, s_, -s_ * ax + c_ * ay]
+                    H[i_imu + 1, [4, 5, 6]] = [-s_, c_, -c_ * ax - s_ * ay]
+                    H[i_imu + 2, 7] = 1
+                if mag:
+                    H[i_mag, 6] = 1
+                K = Pm @ H.T @ arma_inv(H @ Pm @ H.T + R)
+                x = x + (dl + K @ (y - H @ dl))
+            Pn = (np.eye(8) - K @ H) @ Pm
+        return x, Pn
+
+    def state(self):
+        return np.array([self.xy[0], self.xy[1], self.vel[0], self.vel[1], 0.0, 0.0, self.ang, self.ang_speed])

@@ -14,12 +14,22 @@ import numpy as np
 _DIR = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_DIR, "libkfpos_oracle.so")
 
-MODEL_TOA, MODEL_TOA_IMU, MODEL_ML = 0, 1, 2
-ST_UPDATE_SKIPPED, ST_ML_FALLBACK, ST_FEW_RANGES, ST_ML_INIT, ST_NOT_STARTED, ST_NONFINITE = 1, 2, 4, 8, 16, 32
+MODEL_TOA, MODEL_TOA_IMU, MODEL_ML, MODEL_PLANAR = 0, 1, 2, 3
+ST_UPDATE_SKIPPED, ST_ML_FALLBACK, ST_FEW_RANGES, ST_ML_INIT, ST_NOT_STARTED, ST_NONFINITE, ST_SKIPPED = 1, 2, 4, 8, 16, 32, 64
 
 _dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
 _ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 _up = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+
+
+class PlanarConfig(C.Structure):
+    """kfo_planar_config: the XML attributes KalmanFilter::loadConfigurationFiles reads + initialAngle."""
+    _fields_ = [("use_fixed_height", C.c_int), ("fixed_height", C.c_double), ("init_angle", C.c_double),
+                ("px4_height", C.c_double), ("px4_arm_p1", C.c_double), ("px4_arm_p2", C.c_double),
+                ("px4_cov_velocity", C.c_double), ("px4_cov_gyro_z", C.c_double),
+                ("imu_use_fixed_cov_acc", C.c_int), ("imu_cov_acc", C.c_double),
+                ("imu_use_fixed_cov_ang_vel_z", C.c_int), ("imu_cov_ang_vel_z", C.c_double),
+                ("mag_angle_offset", C.c_double), ("mag_cov", C.c_double)]
 
 
 def build(force: bool = False) -> str:
@@ -49,6 +59,12 @@ def lib():
         L.kfo_get_pose.argtypes = [C.c_void_p, C.c_double, _dp, _dp, C.c_void_p, C.c_void_p]
         L.kfo_get_state.argtypes = [C.c_void_p, _dp, _dp]
         L.kfo_set_state.argtypes = [C.c_void_p, _dp, _dp, C.c_int]
+        L.kfo_set_planar.argtypes = [C.c_void_p, C.POINTER(PlanarConfig)]
+        L.kfo_get_height.argtypes = [C.c_void_p, _dp]
+        L.kfo_planar_px4flow.argtypes = [C.c_void_p, _dp, _dp, C.c_int, C.c_void_p, C.c_int]
+        L.kfo_planar_imu.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _dp, C.c_int, C.c_void_p, C.c_int]
+        L.kfo_planar_mag.argtypes = [C.c_void_p, _dp, _dp, C.c_int, C.c_void_p, C.c_int]
+        L.kfo_planar_compass.argtypes = [C.c_void_p, _dp, _dp, C.c_int, C.c_void_p, C.c_int]
         L.kfo_ml_estimate.argtypes = [C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_void_p]
         L.kfo_predict_matrices.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, _dp, _dp]
         L.kfo_inv.argtypes = [C.c_int, _dp, _dp]
@@ -67,7 +83,7 @@ class OracleBank:
     """T independent reference filters (KalmanFilterTOA or repaired KalmanFilterTOAIMU)."""
 
     def __init__(self, model, n_tags, anchors, accel_noise=0.5, jolt=0.5, ignore_worst=False,
-                 cost_threshold=0.5, top_n=0, init_pos=None, n_threads=1):
+                 cost_threshold=0.5, top_n=0, init_pos=None, n_threads=1, planar=None):
         self.model, self.T = model, n_tags
         self.anchors = _f64(anchors)
         self.A = self.anchors.shape[0]
@@ -81,6 +97,9 @@ class OracleBank:
                                    ip.ctypes.data if ip is not None else None)
         lib().kfo_set_anchors(self._h, self.anchors, self.A)
         self.n = lib().kfo_state_dim(self._h)
+        if model == MODEL_PLANAR:
+            self.planar = PlanarConfig(**(planar or {}))
+            lib().kfo_set_planar(self._h, C.byref(self.planar))
 
     def __del__(self):
         if getattr(self, "_h", None):
@@ -108,6 +127,44 @@ class OracleBank:
         st = np.zeros(self.T, dtype=np.uint32)
         lib().kfo_step_imu(self._h, a, c, d, d.size, st.ctypes.data, self.n_threads)
         return st
+
+    # --- KalmanFilter (MODEL_PLANAR): the other four sensors
+    def step_px4flow(self, flow, dt):
+        f = _f64(flow)
+        assert f.shape == (self.T, 5)
+        d = self._dt(dt)
+        st = np.zeros(self.T, dtype=np.uint32)
+        lib().kfo_planar_px4flow(self._h, f, d, d.size, st.ctypes.data, self.n_threads)
+        return st
+
+    def step_planar_imu(self, ang_vel, cov_ang_vel, lin_acc, cov_acc, dt):
+        w, cw, a, ca = _f64(ang_vel), _f64(cov_ang_vel), _f64(lin_acc), _f64(cov_acc)
+        assert w.shape == (self.T, 3) and cw.shape == (self.T, 9) and a.shape == (self.T, 3) and ca.shape == (self.T, 9)
+        d = self._dt(dt)
+        st = np.zeros(self.T, dtype=np.uint32)
+        lib().kfo_planar_imu(self._h, w, cw, a, ca, d, d.size, st.ctypes.data, self.n_threads)
+        return st
+
+    def step_mag(self, mag_xyz, dt):
+        m = _f64(mag_xyz)
+        assert m.shape == (self.T, 3)
+        d = self._dt(dt)
+        st = np.zeros(self.T, dtype=np.uint32)
+        lib().kfo_planar_mag(self._h, m, d, d.size, st.ctypes.data, self.n_threads)
+        return st
+
+    def step_compass(self, compass, dt):
+        c = _f64(compass)
+        assert c.shape == (self.T,)
+        d = self._dt(dt)
+        st = np.zeros(self.T, dtype=np.uint32)
+        lib().kfo_planar_compass(self._h, c, d, d.size, st.ctypes.data, self.n_threads)
+        return st
+
+    def get_height(self):
+        z = np.zeros(self.T)
+        lib().kfo_get_height(self._h, z)
+        return z
 
     def get_pose(self, dt_ahead=0.0):
         pos, cov, vel = np.zeros((self.T, 3)), np.zeros((self.T, 9)), np.zeros((self.T, 3))

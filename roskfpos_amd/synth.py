@@ -135,3 +135,59 @@ class Workload:
         a = np.stack([self.accel(s) for s in range(step0, step0 + n_steps)])
         dt = np.array([self.dt_of(s) for s in range(step0, step0 + n_steps)])
         return r, a, dt
+
+    # -- planar filter sensors (KalmanFilter: PX4Flow, IMU, magnetometer, compass) -----------------
+    # The vehicle heads along its velocity: heading = trajectory angle + pi/2, yaw rate = omega. Sensor frames
+    # follow KalmanFilter::px4flowOutput / imuOutput (KalmanFilter.cpp:558-576): body = R(-heading) * world.
+    PX4_HEIGHT = 0.8        # <px4flow sensorHeight/>
+    PX4_TIME_US = 50000.0   # integration time of one flow sample
+    PX4_SIGMA = 0.02
+    GYRO_SIGMA = 0.01
+    MAG_SIGMA = 0.02
+
+    def heading(self, t: float) -> np.ndarray:
+        return self.omega * t + self.phi + 0.5 * np.pi
+
+    def velocity(self, t: float) -> np.ndarray:
+        ang = self.omega * t + self.phi
+        return np.stack([-self.rho * self.omega * np.sin(ang), self.rho * self.omega * np.cos(ang),
+                         0.02 * np.cos(0.1 * t + self.phi)], axis=1)
+
+    def _body(self, t: float, v: np.ndarray) -> np.ndarray:
+        th = self.heading(t)
+        c, s = np.cos(th), np.sin(th)
+        return np.stack([c * v[:, 0] + s * v[:, 1], -s * v[:, 0] + c * v[:, 1]], axis=1)
+
+    def _noise(self, step: int, base_channel: int, n: int) -> np.ndarray:
+        base = np.uint64(step + 1) * _CH_PER_STEP + np.uint64(base_channel)
+        ch = base + np.uint64(2) * np.arange(n, dtype=np.uint64)
+        return _normal(self._key[:, None], ch[None, :])
+
+    def px4flow(self, step: int) -> np.ndarray:
+        """(T, 5): integrationX, integrationY, integrationRotationZ, integrationTime [us], quality -- the
+        arguments of newPX4FlowMeasurement (KalmanFilter.cpp:102). Every 16th tag reports quality 0."""
+        t = self.time_of(step)
+        vb = self._body(t, self.velocity(t)) + self.PX4_SIGMA * self._noise(step, 210, 2)
+        sec = self.PX4_TIME_US / 1e6
+        gz = self.omega + self.GYRO_SIGMA * self._noise(step, 216, 1)[:, 0]
+        q = np.where((np.arange(self.tag0, self.tag0 + self.n_tags) + step) % 16 == 5, 0.0, 200.0)
+        return np.stack([vb[:, 0] * sec / self.PX4_HEIGHT, vb[:, 1] * sec / self.PX4_HEIGHT, gz * sec,
+                         np.full(self.n_tags, self.PX4_TIME_US), q], axis=1)
+
+    def planar_imu(self, step: int):
+        """angular velocity (T, 3) and body-frame linear acceleration (T, 3) for newIMUMeasurement."""
+        t = self.time_of(step)
+        ab = self._body(t, self.acceleration(t)) + ACC_SIGMA * self._noise(step, 220, 2)
+        w = np.zeros((self.n_tags, 3))
+        w[:, 2] = self.omega + self.GYRO_SIGMA * self._noise(step, 226, 1)[:, 0]
+        a = np.concatenate([ab, np.full((self.n_tags, 1), 9.81)], axis=1)
+        return w, a
+
+    def mag(self, step: int) -> np.ndarray:
+        """(T, 3) magnetometer vector whose atan2(y, x) is the heading."""
+        th = self.heading(self.time_of(step)) + self.MAG_SIGMA * self._noise(step, 230, 1)[:, 0]
+        return np.stack([np.cos(th), np.sin(th), np.full(self.n_tags, -0.4)], axis=1)
+
+    def compass(self, step: int) -> np.ndarray:
+        """(T,) compass heading in radians, unwrapped on purpose (newCompassMeasurement normalises once)."""
+        return self.heading(self.time_of(step)) + self.MAG_SIGMA * self._noise(step, 234, 1)[:, 0]
