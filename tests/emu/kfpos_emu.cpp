@@ -28,6 +28,9 @@ struct kfe_bank {
     std::vector<Imu> imu;
     std::vector<uint32_t> flags;
     std::vector<double> ml_pos, ml_cov, ml_seed; /* model 2: standalone ML estimator */
+    std::vector<Tag8> t8;                        /* model 3: planar filter */
+    std::vector<Latch8> l8;
+    int sensors = 0;                             /* run the SENSORS = true instantiation */
 };
 
 extern "C" {
@@ -49,9 +52,21 @@ kfe_bank *kfe_create(int model, int n_tags, int n_anchors, const double *anchors
     b->pr.ignore_worst = ignore_worst;
     b->pr.top_n = top_n;
     b->pr.use_init_pos = use_init_pos;
+    b->pr.use_fixed_height = b->pr.imu_fixed_cov_acc = b->pr.imu_fixed_cov_w = 0;
+    b->pr.px4_height = b->pr.px4_arm_p1 = b->pr.px4_arm_p2 = b->pr.px4_cov_vel = b->pr.px4_cov_gyro_z = 0.0;
+    b->pr.imu_cov_acc = b->pr.imu_cov_w = b->pr.mag_offset = b->pr.mag_cov = 0.0;
     b->flags.assign(n_tags, 0u);
     auto ip = [&](int t, int k) { return use_init_pos ? (init_pos ? init_pos[3 * t + k] : 0.0) : NAN; };
-    if (model == 2) {
+    if (model == 3) {
+        b->t8.resize(n_tags);
+        b->l8.resize(n_tags);
+        for (int t = 0; t < n_tags; ++t) {
+            std::memset(&b->t8[t], 0, sizeof(Tag8));
+            std::memset(&b->l8[t], 0, sizeof(Latch8));
+            b->t8[t].xy[0] = ip(t, 0);
+            b->t8[t].xy[1] = ip(t, 1);
+        }
+    } else if (model == 2) {
         b->ml_pos.assign((size_t)3 * n_tags, NAN);
         b->ml_cov.assign((size_t)6 * n_tags, NAN);
         b->ml_seed.assign((size_t)3 * n_tags, 0.0);
@@ -82,6 +97,17 @@ kfe_bank *kfe_create(int model, int n_tags, int n_anchors, const double *anchors
 }
 void kfe_destroy(kfe_bank *b) { delete b; }
 void kfe_set_static(kfe_bank *b, int on) { b->use_static = on; }
+/* cfg: the 14 fields of kfpos_planar_config in order, as doubles */
+void kfe_set_planar(kfe_bank *b, const double *cfg, int sensors) {
+    Params &p = b->pr;
+    p.use_fixed_height = cfg[0] != 0;
+    p.px4_height = cfg[3]; p.px4_arm_p1 = cfg[4]; p.px4_arm_p2 = cfg[5]; p.px4_cov_vel = cfg[6]; p.px4_cov_gyro_z = cfg[7];
+    p.imu_fixed_cov_acc = cfg[8] != 0; p.imu_cov_acc = cfg[9];
+    p.imu_fixed_cov_w = cfg[10] != 0; p.imu_cov_w = cfg[11];
+    p.mag_offset = cfg[12]; p.mag_cov = cfg[13];
+    b->sensors = sensors;
+    for (Tag8 &tg : b->t8) { tg.z = cfg[1]; tg.ang = cfg[2]; tg.om = 0.0; }
+}
 
 static void fill_scratch(const kfe_bank *b, const int32_t *mm, const double *err, std::vector<double> &buf,
                          Scratch &sc) {
@@ -107,6 +133,11 @@ static uint32_t step_static(kfe_bank *b, int t, const int32_t *mm, const double 
         sc.e[a] = err[a];
         sc.w[a] = 0.0;
     }
+    if (b->model == 3) {
+        const uint32_t rows = ROW_RANGING | b->l8[t].has;
+        return b->sensors ? step_planar8<true>(b->t8[t], sc, b->pr, lag, rows, b->l8[t])
+                          : step_planar8<false>(b->t8[t], sc, b->pr, lag, rows, b->l8[t]);
+    }
     if (b->model == 2) return step_ml(&b->ml_pos[3 * t], &b->ml_cov[6 * t], sc, b->pr, &b->ml_seed[3 * t]);
     if (b->model == 0 && !b->full) return step_toa6(b->t6s[t], sc, b->pr, lag);
     if (b->model == 0) return step_toa6(b->t6f[t], sc, b->pr, lag);
@@ -124,12 +155,20 @@ void kfe_step_toa(kfe_bank *b, const int32_t *range_mm, const double *err_est, c
         const double *err = err_est + (size_t)t * b->A;
         const double lag = dt[dt_len > 1 ? t : 0];
         uint32_t st;
+        if (dt_len > 1 && lag < 0) { /* no epoch for this tag */
+            if (status) status[t] = ST_SKIPPED;
+            continue;
+        }
         if (b->use_static && b->A == 8) st = step_static<8>(b, t, mm, err, lag);
         else if (b->use_static && b->A == 16) st = step_static<16>(b, t, mm, err, lag);
         else if (b->use_static && b->A == 4) st = step_static<4>(b, t, mm, err, lag);
         else {
             fill_scratch(b, mm, err, buf, sc);
-            if (b->model == 2) st = step_ml(&b->ml_pos[3 * t], &b->ml_cov[6 * t], sc, b->pr, &b->ml_seed[3 * t]);
+            if (b->model == 3) {
+                const uint32_t rows = ROW_RANGING | b->l8[t].has;
+                st = b->sensors ? step_planar8<true>(b->t8[t], sc, b->pr, lag, rows, b->l8[t])
+                                : step_planar8<false>(b->t8[t], sc, b->pr, lag, rows, b->l8[t]);
+            } else if (b->model == 2) st = step_ml(&b->ml_pos[3 * t], &b->ml_cov[6 * t], sc, b->pr, &b->ml_seed[3 * t]);
             else if (b->model == 0 && !b->full) st = step_toa6(b->t6s[t], sc, b->pr, lag);
             else if (b->model == 0) st = step_toa6(b->t6f[t], sc, b->pr, lag);
             else st = step_imu9(b->t9[t], sc, b->pr, lag, true, b->imu[t]);
@@ -162,6 +201,53 @@ void kfe_step_imu(kfe_bank *b, const double *accel, const double *cov, const dou
     }
 }
 
+/* The other four sensor entry points of the planar filter. kind: 1 PX4Flow (T x 5), 2 IMU (T x 24: angular
+ * velocity 3, its covariance 9, linear acceleration 3, its covariance 9), 3 magnetometer (T x 3), 4 compass (T). */
+void kfe_planar_sensor(kfe_bank *b, int kind, const double *data, const double *dt, int dt_len, uint32_t *status) {
+    if (b->model != 3) return;
+    Scratch sc{nullptr, nullptr, nullptr, 1};
+    for (int t = 0; t < b->T; ++t) {
+        const double lag = dt[dt_len > 1 ? t : 0];
+        if (dt_len > 1 && lag < 0) {
+            if (status) status[t] = ST_SKIPPED;
+            continue;
+        }
+        Latch8 &lt = b->l8[t];
+        uint32_t rows = 0;
+        if (kind == 1) {
+            double m[5];
+            if (!px4_sample(b->pr, data + 5 * (size_t)t, m)) {
+                if (status) status[t] = ST_SKIPPED;
+                continue;
+            }
+            for (int k = 0; k < 5; ++k) lt.px4[k] = m[k];
+            lt.has |= ROW_PX4;
+            rows = ROW_PX4;
+        } else if (kind == 2) {
+            const double *d = data + 24 * (size_t)t;
+            imu_sample8(b->pr, d, d + 3, d + 12, d + 15, lt.imu);
+            lt.has |= ROW_IMU;
+            rows = ROW_IMU;
+        } else if (kind == 3) {
+            lt.mag[0] = atan2(data[3 * (size_t)t + 1], data[3 * (size_t)t]) - b->pr.mag_offset; /* KalmanFilter.cpp:188 */
+            lt.mag[1] = b->pr.mag_cov;
+            lt.has |= ROW_MAG;
+            rows = ROW_MAG;
+        } else {
+            lt.mag[0] = normalize_angle(data[t]); /* KalmanFilter.cpp:207 */
+            lt.mag[1] = b->pr.mag_cov;
+            lt.has |= ROW_MAG;
+            rows = ROW_MAG | (lt.has & (ROW_PX4 | ROW_IMU));
+        }
+        const uint32_t st = step_planar8<true>(b->t8[t], sc, b->pr, lag, rows, lt);
+        b->flags[t] |= FL_STARTED;
+        if (status) status[t] = st;
+    }
+}
+void kfe_get_height(const kfe_bank *b, double *z) {
+    for (int t = 0; t < b->T; ++t) z[t] = b->t8[t].z;
+}
+
 /* Emulate KFPOS_STORE_F32: what the step kernels keep in HBM between epochs is rounded to float
  * (covariance when what&1, velocity when what&2); positions always stay double. */
 void kfe_round_storage(kfe_bank *b, int what) {
@@ -188,6 +274,16 @@ void kfe_round_storage(kfe_bank *b, int what) {
 
 /* x: T*n ([pos, vel(, 0)]), P: T*n*n full row-major */
 void kfe_get_state(const kfe_bank *b, double *x, double *P) {
+    if (b->model == 3) {
+        for (int t = 0; t < b->T; ++t) {
+            const Tag8 &tg = b->t8[t];
+            const double s8[8] = {tg.xy[0], tg.xy[1], tg.vel[0], tg.vel[1], 0.0, 0.0, tg.ang, tg.om};
+            for (int k = 0; k < 8; ++k) x[8 * (size_t)t + k] = s8[k];
+            for (int i = 0; i < 8; ++i)
+                for (int j = 0; j < 8; ++j) P[64 * (size_t)t + 8 * i + j] = tg.P(i, j);
+        }
+        return;
+    }
     if (b->model == 2) {
         for (int t = 0; t < b->T; ++t) {
             const double *c = &b->ml_cov[6 * t];
@@ -220,6 +316,16 @@ void kfe_get_pose(const kfe_bank *b, double dt_ahead, double *pos, double *cov3x
         if (!(b->flags[t] & FL_STARTED)) {
             for (int k = 0; k < 3; ++k) { pos[3 * t + k] = NAN; vel[3 * t + k] = NAN; }
             for (int k = 0; k < 9; ++k) cov3x3[9 * t + k] = NAN;
+            continue;
+        }
+        if (b->model == 3) {
+            double x8[8];
+            Cov<8, true> Pp;
+            pose8(b->t8[t], dt_ahead, b->pr.accel_noise, b->pr.jolt, x8, Pp);
+            const double c[9] = {Pp(0, 0), Pp(0, 1), 0, Pp(0, 1), Pp(1, 1), 0, 0, 0, 0.01};
+            pos[3 * t] = x8[0]; pos[3 * t + 1] = x8[1]; pos[3 * t + 2] = b->t8[t].z;
+            vel[3 * t] = x8[2]; vel[3 * t + 1] = x8[3]; vel[3 * t + 2] = 0.0;
+            for (int k = 0; k < 9; ++k) cov3x3[9 * t + k] = c[k];
             continue;
         }
         if (b->model == 1) pose9(b->t9[t], dt_ahead, b->pr.jolt, pos + 3 * t, v, cov3x3 + 9 * t);

@@ -1,0 +1,150 @@
+"""Shared driver for the 8-state planar filter (KalmanFilter, ALGORITHM_KF) parity tests: one seeded trace
+interleaving the five sensor entry points, replayed through the oracle, the host emulation of the kernel body and
+(GPU tests) the HIP library."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+import oracle_py
+from impls import emu_lib
+from roskfpos_amd.synth import Workload
+
+CFG = dict(use_fixed_height=1, fixed_height=1.0, init_angle=0.3, px4_height=Workload.PX4_HEIGHT, px4_arm_p1=0.05,
+           px4_arm_p2=-0.02, px4_cov_velocity=0.002, px4_cov_gyro_z=0.001, imu_use_fixed_cov_acc=0, imu_cov_acc=0.02,
+           imu_use_fixed_cov_ang_vel_z=1, imu_cov_ang_vel_z=0.0005, mag_angle_offset=0.1, mag_cov=0.01)
+CFG_ORDER = ["use_fixed_height", "fixed_height", "init_angle", "px4_height", "px4_arm_p1", "px4_arm_p2",
+             "px4_cov_velocity", "px4_cov_gyro_z", "imu_use_fixed_cov_acc", "imu_cov_acc",
+             "imu_use_fixed_cov_ang_vel_z", "imu_cov_ang_vel_z", "mag_angle_offset", "mag_cov"]
+
+
+def _dt(dt, T):
+    d = np.atleast_1d(np.asarray(dt, dtype=np.float64))
+    assert d.size in (1, T)
+    return np.ascontiguousarray(d)
+
+
+class PlanarOracle:
+    def __init__(self, w, cfg, init, accel_noise=0.5, jolt=0.5):
+        self.b = oracle_py.OracleBank(oracle_py.MODEL_PLANAR, w.n_tags, w.anchors, accel_noise=accel_noise, jolt=jolt,
+                                      init_pos=init, planar=cfg, n_threads=4)
+        for name in ("step_toa", "step_px4flow", "step_planar_imu", "step_mag", "step_compass", "get_state",
+                     "get_height", "get_pose"):
+            setattr(self, name, getattr(self.b, name))
+
+
+class PlanarEmu:
+    """kfpos_core.h's step_planar8 compiled for the host. sensors: run the SENSORS = true instantiation for the
+    ranging epochs too (the four sensor entry points always do)."""
+
+    def __init__(self, w, cfg, init, accel_noise=0.5, jolt=0.5, sensors=True, static=False):
+        L = emu_lib()
+        dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+        L.kfe_set_planar.argtypes = [C.c_void_p, dp, C.c_int]
+        L.kfe_planar_sensor.argtypes = [C.c_void_p, C.c_int, dp, dp, C.c_int, C.c_void_p]
+        L.kfe_get_height.argtypes = [C.c_void_p, dp]
+        self.T, self.A = w.n_tags, w.n_anchors
+        ipt = None if init is None else np.ascontiguousarray(init, dtype=np.float64)
+        self.h = L.kfe_create(3, self.T, self.A, np.ascontiguousarray(w.anchors), accel_noise, jolt, 0, 0.5, 0,
+                              int(init is not None), None if ipt is None else ipt.ctypes.data)
+        L.kfe_set_planar(self.h, np.array([float(cfg.get(k, 0.0)) for k in CFG_ORDER]), int(sensors))
+        L.kfe_set_static(self.h, int(static))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            emu_lib().kfe_destroy(self.h)
+            self.h = None
+
+    def step_toa(self, r, err, dt):
+        st = np.zeros(self.T, dtype=np.uint32)
+        d = _dt(dt, self.T)
+        emu_lib().kfe_step_toa(self.h, np.ascontiguousarray(r, dtype=np.int32),
+                               np.ascontiguousarray(err, dtype=np.float64), d, d.size, st.ctypes.data)
+        return st
+
+    def _sensor(self, kind, data, dt):
+        st = np.zeros(self.T, dtype=np.uint32)
+        d = _dt(dt, self.T)
+        emu_lib().kfe_planar_sensor(self.h, kind, np.ascontiguousarray(data, dtype=np.float64), d, d.size, st.ctypes.data)
+        return st
+
+    def step_px4flow(self, flow, dt):
+        return self._sensor(1, flow, dt)
+
+    def step_planar_imu(self, ang_vel, cov_ang_vel, lin_acc, cov_acc, dt):
+        return self._sensor(2, np.concatenate([ang_vel, cov_ang_vel, lin_acc, cov_acc], axis=1), dt)
+
+    def step_mag(self, mag_xyz, dt):
+        return self._sensor(3, mag_xyz, dt)
+
+    def step_compass(self, compass, dt):
+        return self._sensor(4, compass, dt)
+
+    def get_state(self):
+        x, P = np.zeros((self.T, 8)), np.zeros((self.T, 8, 8))
+        emu_lib().kfe_get_state(self.h, x, P)
+        return x, P
+
+    def get_height(self):
+        z = np.zeros(self.T)
+        emu_lib().kfe_get_height(self.h, z)
+        return z
+
+    def get_pose(self, dt_ahead=0.0):
+        pos, cov, vel = np.zeros((self.T, 3)), np.zeros((self.T, 9)), np.zeros((self.T, 3))
+        emu_lib().kfe_get_pose(self.h, dt_ahead, pos, cov, vel)
+        return pos, cov.reshape(self.T, 3, 3), vel, None
+
+
+def epoch_ranges(w, s, edge):
+    r = w.ranges_mm(s)
+    if edge:
+        if s % 7 == 3:
+            r[:, 1] = -1
+        if s % 11 == 5:
+            r[::3, 2:] = 0      # two ranges left: below the 2-D solver's minimum of three
+        if s % 13 == 6:
+            r[2::5, 3:] = 0     # exactly three ranges
+        if s % 23 == 9:
+            r[1::4, :] = 0
+    return r
+
+
+def run_trace(impls, w, S, sensors=(), edge=True, collect=None):
+    """Drive every impl in `impls` with the same interleaved trace. Returns the list of per-call status arrays
+    per impl. collect(s, impls) is called after each ranging epoch."""
+    T = w.n_tags
+    err = w.err_est()
+    cw, ca = np.tile(np.eye(3).ravel() * 1e-4, (T, 1)), w.accel_cov()
+    ca[:, 1] = ca[:, 3] = 0.002  # correlated accelerometer axes
+    out = [[] for _ in impls]
+
+    def each(fn):
+        for k, im in enumerate(impls):
+            out[k].append(fn(im))
+
+    for s in range(S):
+        dts = np.full(T, w.dt_of(s))
+        if "imu" in sensors and s >= 2:
+            wv, la = w.planar_imu(s)
+            each(lambda im: im.step_planar_imu(wv, cw, la, ca, 0.01))
+            dts = dts - 0.01
+        if "px4" in sensors and s >= 3:
+            f = w.px4flow(s)
+            each(lambda im: im.step_px4flow(f, 0.01))
+            # a dropped sample (quality 0) does not touch the reference's time stamp
+            dts = np.where(f[:, 4] == 0, dts, dts - 0.01)
+        if "mag" in sensors and s >= 4 and s % 2 == 0:
+            m = w.mag(s)
+            each(lambda im: im.step_mag(m, 0.005))
+            dts = dts - 0.005
+        if "compass" in sensors and s >= 5 and s % 2 == 1:
+            c = w.compass(s)
+            each(lambda im: im.step_compass(c, 0.005))
+            dts = dts - 0.005
+        r = epoch_ranges(w, s, edge)
+        each(lambda im: im.step_toa(r, err, dts))
+        if collect:
+            collect(s, impls)
+    return out
