@@ -41,6 +41,9 @@ extern "C" {
 #define KFPOS_MODEL_ML      2 /* ALGORITHM_ML -> MLLocation as the estimator (MLLocation.cpp:421-486): 3-D, variant NORMAL
                                (top_n = 0) or IGNORE_N (top_n = numRangingsToIgnore); state = position, P = its 3x3
                                covariance; dt is ignored, use_init_pos selects the solver's seed ({1,1,4} otherwise) */
+#define KFPOS_MODEL_PLANAR  3 /* ALGORITHM_KF -> KalmanFilter (KalmanFilter.cpp): 8 states [x y vx vy ax ay theta omega] at a
+                               fixed height, fed by ranging epochs and, optionally, PX4Flow / IMU / magnetometer /
+                               compass samples (kfpos_step_sensor). Configure with kfpos_set_planar() before stepping */
 
 /* ---- storage precision of the covariance and of the measurements in HBM; arithmetic is always f64 ----
  * Positions and velocities are kept as double in both modes, ranges are exact integer mm. F32 rounds the
@@ -84,6 +87,37 @@ typedef struct kfpos_config {
     int32_t device;         /* HIP device ordinal */
 } kfpos_config;
 
+/* KFPOS_MODEL_PLANAR only: the attributes KalmanFilter::loadConfigurationFiles reads from the four XML
+ * parameters (KalmanFilter.cpp:748-842; config_uwb.xml / config_px4flow.xml / config_imu.xml / config_mag.xml
+ * of src/kfpos/config) plus the constructor's initialAngle (KalmanFilter.h:32). */
+typedef struct kfpos_planar_config {
+    int32_t use_fixed_height;  /* <uwb useFixedHeight/>: 1 = 2-D ML initialisation at fixed_height, 0 = 3-D ML
+                                  initialisation whose z becomes the height (KalmanFilter.cpp:252-258) */
+    double  fixed_height;      /* <uwb fixedHeight/> = mUWBtagZ */
+    double  init_angle;        /* initialAngle [initAngle] */
+    double  px4_height;        /* <px4flow sensorHeight/> */
+    double  px4_arm_p1;        /* <px4flow armP0/> */
+    double  px4_arm_p2;        /* <px4flow armP1/> */
+    double  px4_cov_velocity;  /* <px4flow covarianceVelocity/> */
+    double  px4_cov_gyro_z;    /* <px4flow covarianceGyroZ/> */
+    int32_t imu_use_fixed_cov_acc;       /* <imu useFixedCovarianceAcceleration/> */
+    double  imu_cov_acc;                 /* <imu covarianceAcceleration/> */
+    int32_t imu_use_fixed_cov_ang_vel_z; /* <imu useFixedCovarianceAngularVelocityZ/> */
+    double  imu_cov_ang_vel_z;           /* <imu covarianceAngularVelocityZ/> */
+    double  mag_angle_offset;  /* <mag angleOffset/> */
+    double  mag_cov;           /* <mag covarianceMag/> */
+} kfpos_planar_config;
+
+/* sensor kinds of kfpos_step_sensor: the other four entry points of PositionEstimationAlgorithm */
+#define KFPOS_SENSOR_PX4FLOW 1 /* newPX4FlowMeasurement (KalmanFilter.cpp:102-135): 5 values per tag = integrationX,
+                                  integrationY, integrationRotationZ, integrationTime [us], quality. A sample with
+                                  quality 0 is dropped on entry (status KFPOS_ST_SKIPPED) */
+#define KFPOS_SENSOR_IMU     2 /* newIMUMeasurement (:139-182): 24 values = angularVelocity[3], its covariance[9],
+                                  linearAcceleration[3], its covariance[9] (row-major 3x3) */
+#define KFPOS_SENSOR_MAG     3 /* newMAGMeasurement (:185-199): 3 values = mag x, y, z (its covariance argument is
+                                  ignored by the reference and is not part of this ABI) */
+#define KFPOS_SENSOR_COMPASS 4 /* newCompassMeasurement (:201-229): 1 value = heading in radians */
+
 typedef struct kfpos_handle kfpos_handle;
 
 /* ---- lifetime: PosGenerator::setAlgorithm (Posgenerator.cpp:510-538) ---- */
@@ -98,6 +132,10 @@ int kfpos_set_anchors(kfpos_handle *h, const double *xyz, const int32_t *ids, in
 /* Per-tag fixed start positions, n_tags*3 doubles (batched form of the initialPosition ctor argument).
  * Only before the first step and only with use_init_pos = 1. */
 int kfpos_set_init_positions(kfpos_handle *h, const double *xyz);
+
+/* KFPOS_MODEL_PLANAR: what KalmanFilter::init() loads. Before the first step; every tag starts at
+ * fixed_height / init_angle. KFPOS_ERR_MODEL on other models. */
+int kfpos_set_planar(kfpos_handle *h, const kfpos_planar_config *cfg);
 
 /* size in bytes of kfpos_real for this handle (8 or 4) */
 int kfpos_real_size(const kfpos_handle *h);
@@ -133,6 +171,17 @@ int kfpos_step_toa_imu(kfpos_handle *h, const int32_t *range_mm, const void *err
                        const void *accel, const void *cov,
                        const double *dt, int32_t dt_len, uint32_t *status);
 
+/* KFPOS_MODEL_PLANAR: one sample of one of the other four sensors for every tag = T calls of
+ * newPX4FlowMeasurement / newIMUMeasurement / newMAGMeasurement / newCompassMeasurement: latch the sample, then
+ * predict + update with that sensor's rows (the compass call also carries the latched PX4Flow and IMU samples,
+ * KalmanFilter.cpp:213-226). From then on every ranging epoch of that tag carries its latched samples
+ * (:84-98). data: n_tags x C doubles row-major, C by kind (KFPOS_SENSOR_*); dt / dt_len / status as in
+ * kfpos_step_toa. Other models: the reference's empty virtuals, returns KFPOS_OK and status 0. */
+int kfpos_step_sensor(kfpos_handle *h, int32_t kind, const double *data,
+                      const double *dt, int32_t dt_len, uint32_t *status);
+/* mUWBtagZ of every tag (n_tags doubles): the configured height, or the ML initialisation's z */
+int kfpos_get_height(kfpos_handle *h, double *z);
+
 /* getPose for every tag (KalmanFilterTOA.cpp:438-473, KalmanFilterTOAIMU.cpp:476-510): predict-only
  * extrapolation by dt_ahead, filter state untouched. pos n_tags x 3, cov3x3 n_tags x 9 (position block of
  * the predicted covariance; the only block stateToPose fills, KalmanFilterTOA.cpp:159-183), vel n_tags x 3
@@ -152,9 +201,10 @@ int kfpos_get_pose_each(kfpos_handle *h, const double *dt_ahead, double *pos, do
 int kfpos_get_predicted(kfpos_handle *h, const double *dt_ahead, int32_t dt_len, double *x, double *P,
                         uint32_t *status);
 
-/* Raw filter members for tests and checkpoint/restore: x n_tags x n ([p, v(, a = 0)]),
- * P n_tags x n x n row-major, double. n = kfpos_state_dim(). flags: n_tags words (bit 0 started,
- * bit 1 has latched IMU), may be NULL. */
+/* Raw filter members for tests and checkpoint/restore: x n_tags x n ([p, v(, a = 0)]; planar:
+ * [x y vx vy 0 0 theta omega]), P n_tags x n x n row-major, double. n = kfpos_state_dim(). flags: n_tags
+ * words (bit 0 started, bit 1 has latched IMU; planar: bits 5..7 latched PX4Flow / IMU / magnetometer), may
+ * be NULL. */
 int kfpos_state_dim(const kfpos_handle *h);
 int kfpos_get_state(kfpos_handle *h, double *x, double *P, uint32_t *flags);
 int kfpos_set_state(kfpos_handle *h, const double *x, const double *P, const uint32_t *flags);
@@ -177,6 +227,9 @@ int kfpos_step_imu_dev(kfpos_handle *h, const void *accel, const void *cov,
 int kfpos_step_toa_imu_dev(kfpos_handle *h, const int32_t *range_mm, const void *err_est,
                            const void *accel, const void *cov, int32_t latch,
                            const double *dt, double dt_shared, uint32_t *status, void *stream);
+/* kfpos_step_sensor on device buffers: data is component-major [C][n_tags] doubles */
+int kfpos_step_sensor_dev(kfpos_handle *h, int32_t kind, const double *data,
+                          const double *dt, double dt_shared, uint32_t *status, void *stream);
 int kfpos_get_pose_dev(kfpos_handle *h, double dt_ahead, double *pos, double *cov3x3, double *vel,
                        uint32_t *status, void *stream);
 

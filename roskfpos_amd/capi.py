@@ -15,7 +15,9 @@ import numpy as np
 _DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KFPOS_LIB_PATH") or os.path.join(_DIR, "csrc", "libkfpos_hip.so")  # override: A/B builds
 
-MODEL_TOA, MODEL_TOA_IMU, MODEL_ML = 0, 1, 2
+MODEL_TOA, MODEL_TOA_IMU, MODEL_ML, MODEL_PLANAR = 0, 1, 2, 3
+SENSOR_PX4FLOW, SENSOR_IMU, SENSOR_MAG, SENSOR_COMPASS = 1, 2, 3, 4
+_SENSOR_WIDTH = {1: 5, 2: 24, 3: 3, 4: 1}
 STORE_F64, STORE_F32, STORE_MIXED = 0, 1, 2
 MAX_ANCHORS = 64
 ST_UPDATE_SKIPPED, ST_ML_FALLBACK, ST_FEW_RANGES, ST_ML_INIT, ST_NOT_STARTED, ST_NONFINITE = 1, 2, 4, 8, 16, 32
@@ -29,6 +31,7 @@ EXPORTS = [
     "kfpos_state_dim", "kfpos_get_state", "kfpos_set_state", "kfpos_step_toa_dev", "kfpos_step_imu_dev",
     "kfpos_step_toa_imu_dev", "kfpos_get_pose_dev", "kfpos_run_trace_dev", "kfpos_last_error",
     "kfpos_strerror", "kfpos_version", "kfpos_timing_begin", "kfpos_timing_end",
+    "kfpos_set_planar", "kfpos_step_sensor", "kfpos_step_sensor_dev", "kfpos_get_height",
 ]
 
 
@@ -41,6 +44,16 @@ class _Config(C.Structure):
                 ("storage", C.c_int32), ("accel_noise", C.c_double), ("jolt", C.c_double),
                 ("ignore_worst", C.c_int32), ("cost_threshold", C.c_double), ("top_n", C.c_int32),
                 ("use_init_pos", C.c_int32), ("init_pos", C.c_double * 3), ("device", C.c_int32)]
+
+
+class PlanarConfig(C.Structure):
+    """kfpos_planar_config: what KalmanFilter::loadConfigurationFiles reads + initialAngle."""
+    _fields_ = [("use_fixed_height", C.c_int32), ("fixed_height", C.c_double), ("init_angle", C.c_double),
+                ("px4_height", C.c_double), ("px4_arm_p1", C.c_double), ("px4_arm_p2", C.c_double),
+                ("px4_cov_velocity", C.c_double), ("px4_cov_gyro_z", C.c_double),
+                ("imu_use_fixed_cov_acc", C.c_int32), ("imu_cov_acc", C.c_double),
+                ("imu_use_fixed_cov_ang_vel_z", C.c_int32), ("imu_cov_ang_vel_z", C.c_double),
+                ("mag_angle_offset", C.c_double), ("mag_cov", C.c_double)]
 
 
 _lib = None
@@ -83,6 +96,10 @@ def load():
     L.kfpos_get_pose_dev.argtypes = [vp, f64, vp, vp, vp, vp, vp]
     L.kfpos_run_trace_dev.argtypes = [vp, i32, vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, vp, C.c_int64,
                                       vp, vp, vp, vp]
+    L.kfpos_set_planar.argtypes = [vp, C.POINTER(PlanarConfig)]
+    L.kfpos_step_sensor.argtypes = [vp, i32, vp, vp, i32, vp]
+    L.kfpos_step_sensor_dev.argtypes = [vp, i32, vp, vp, f64, vp, vp]
+    L.kfpos_get_height.argtypes = [vp, vp]
     L.kfpos_timing_begin.argtypes = [vp, vp]
     L.kfpos_timing_end.argtypes = [vp, vp, C.POINTER(C.c_float)]
     L.kfpos_last_error.restype = C.c_char_p
@@ -106,7 +123,7 @@ class KfposBank:
 
     def __init__(self, model, n_tags, anchors, storage=STORE_F64, accel_noise=0.5, jolt=0.5,
                  ignore_worst=False, cost_threshold=0.5, top_n=0, init_pos=None, device=0,
-                 max_anchors=None):
+                 max_anchors=None, planar=None):
         self._h = None
         self.lib = load()
         anchors = np.ascontiguousarray(anchors, dtype=np.float64)
@@ -132,6 +149,9 @@ class KfposBank:
         self._h = h
         self._chk(self.lib.kfpos_init(h))
         self._chk(self.lib.kfpos_set_anchors(h, anchors.ctypes.data, None, anchors.shape[0]))
+        if model == MODEL_PLANAR:  # KalmanFilter::init(): the XML configuration (dict of PlanarConfig fields)
+            self.planar = PlanarConfig(**(planar or {}))
+            self._chk(self.lib.kfpos_set_planar(h, C.byref(self.planar)))
         if per_tag is not None:
             self._chk(self.lib.kfpos_set_init_positions(h, per_tag.ctypes.data))
         self.n = self.lib.kfpos_state_dim(h)
@@ -190,6 +210,32 @@ class KfposBank:
                                               c.ctypes.data, d.ctypes.data, d.size, st.ctypes.data))
         return st
 
+    def step_sensor(self, kind, data, dt):
+        """KalmanFilter's other four entry points (MODEL_PLANAR): SENSOR_PX4FLOW (T, 5), SENSOR_IMU (T, 24),
+        SENSOR_MAG (T, 3), SENSOR_COMPASS (T,)."""
+        x = np.ascontiguousarray(data, dtype=np.float64).reshape(self.T, -1)
+        assert x.shape[1] == _SENSOR_WIDTH[kind]
+        d, st = self._dt(dt), np.zeros(self.T, dtype=np.uint32)
+        self._chk(self.lib.kfpos_step_sensor(self._h, kind, x.ctypes.data, d.ctypes.data, d.size, st.ctypes.data))
+        return st
+
+    def step_px4flow(self, flow, dt):
+        return self.step_sensor(SENSOR_PX4FLOW, flow, dt)
+
+    def step_planar_imu(self, ang_vel, cov_ang_vel, lin_acc, cov_acc, dt):
+        return self.step_sensor(SENSOR_IMU, np.concatenate([ang_vel, cov_ang_vel, lin_acc, cov_acc], axis=1), dt)
+
+    def step_mag(self, mag_xyz, dt):
+        return self.step_sensor(SENSOR_MAG, mag_xyz, dt)
+
+    def step_compass(self, compass, dt):
+        return self.step_sensor(SENSOR_COMPASS, compass, dt)
+
+    def get_height(self):
+        z = np.zeros(self.T)
+        self._chk(self.lib.kfpos_get_height(self._h, z.ctypes.data))
+        return z
+
     def get_pose(self, dt_ahead=0.0):
         pos, cov, vel = np.zeros((self.T, 3)), np.zeros((self.T, 9)), np.zeros((self.T, 3))
         st = np.zeros(self.T, dtype=np.uint32)
@@ -242,6 +288,10 @@ class KfposBank:
         self._chk(self.lib.kfpos_step_toa_imu_dev(self._h, _ptr(range_mm), _ptr(err_est), _ptr(accel),
                                                   _ptr(cov), int(latch), _ptr(dt_dev), float(dt),
                                                   _ptr(status), _ptr(stream)))
+
+    def step_sensor_dev(self, kind, data, dt, status=None, stream=None, dt_dev=None):
+        self._chk(self.lib.kfpos_step_sensor_dev(self._h, int(kind), _ptr(data), _ptr(dt_dev), float(dt),
+                                                 _ptr(status), _ptr(stream)))
 
     def get_pose_dev(self, dt_ahead, pos=None, cov=None, vel=None, status=None, stream=None):
         self._chk(self.lib.kfpos_get_pose_dev(self._h, float(dt_ahead), _ptr(pos), _ptr(cov), _ptr(vel),

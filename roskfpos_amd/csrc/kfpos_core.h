@@ -1263,13 +1263,14 @@ KFPOS_FN void ml2d_covariance(const double p[2], double z, const SC &sc, const P
 }
 
 /* One scalar row of the linearised update, processed sequentially (rows with uncorrelated noise may be
- * absorbed one after the other): h has NNZ non-zeros at the compile-time columns IX, noise variance R,
+ * absorbed one after the other): h has its non-zeros hv at the compile-time columns IX, noise variance R,
  * linearised innovation r. dl is the running state offset from the prediction, P the running covariance.
  *   s = P h; alpha = 1 / (h.s + R); dl += alpha s (r - h.dl); P -= alpha s s'.
  * Also accumulates what the cost and delta' pinv(P) delta need. `on` = false is a branch-free no-op. */
-template <int NNZ>
-KFPOS_FN void seq_row8(Cov<8, true> &P, double dl[8], const int (&ix)[NNZ], const double (&hv)[NNZ], double R,
-                       double r, bool on) {
+template <int... IX>
+KFPOS_FN void seq_row8(Cov<8, true> &P, double dl[8], const double (&hv)[sizeof...(IX)], double R, double r, bool on) {
+    constexpr int NNZ = sizeof...(IX);
+    constexpr int ix[NNZ] = {IX...}; /* compile-time columns: every array index below is static after unrolling */
     double h[NNZ], s[8], hs = on ? R : 1.0, hd = 0.0;
     KFPOS_UNROLL
     for (int k = 0; k < NNZ; ++k) h[k] = on ? hv[k] : 0.0; /* an absent row may carry garbage (0/0 variances) */
@@ -1293,13 +1294,24 @@ KFPOS_FN void seq_row8(Cov<8, true> &P, double dl[8], const int (&ix)[NNZ], cons
     }
 }
 /* h . dl for a sparse row */
-template <int NNZ>
-KFPOS_FN double row_dot8(const double dl[8], const int (&ix)[NNZ], const double (&hv)[NNZ]) {
+template <int... IX>
+KFPOS_FN double row_dot8(const double dl[8], const double (&hv)[sizeof...(IX)]) {
+    constexpr int NNZ = sizeof...(IX);
+    constexpr int ix[NNZ] = {IX...};
     double v = 0.0;
     KFPOS_UNROLL
     for (int k = 0; k < NNZ; ++k) v += hv[k] * dl[ix[k]];
     return v;
 }
+
+/* Read-only view of a packed 8x8 covariance parked outside the register file (LDS on the GPU, element k at
+ * base[k * stride]): the sensor-row update needs the predicted covariance of every iteration while it
+ * downdates a working copy, and two register-resident copies do not fit next to the epoch. */
+struct CovSpill8 {
+    double *base;
+    int stride;
+    KFPOS_HD double operator()(int i, int j) const { return base[Cov<8, true>::idx(i, j) * stride]; }
+};
 
 struct Iekf8Out {
     double x[8];
@@ -1329,8 +1341,8 @@ KFPOS_FN void iekf8_weights(const double xhat[8], double z, SC &sc, const Params
  * The sensor rows follow one at a time (seq_row8); the two accelerometer rows, whose noise is correlated,
  * go as one 2x2 block. delta' pinv(P) delta of the cost is u_tot . dl - dl' M_tot dl, summed row group by
  * row group (w = u - M P w for the joint solve, so w' P w = (u - M dl) . dl). */
-template <bool SENSORS, class SC>
-KFPOS_FN void iekf8(const double xhat[8], double z, const Cov<8, true> &P, Cov<8, true> &Pout, SC &sc,
+template <bool SENSORS, class PM, class SC>
+KFPOS_FN void iekf8(const double xhat[8], double z, const PM &P, Cov<8, true> &Pout, SC &sc,
                     const Params &pr, uint32_t rows, const Latch8 &lt, double t, Iekf8Out &o) {
     const bool has_r = (rows & ROW_RANGING) != 0;
     const uint64_t drop = has_r ? 0ull : ~0ull;
@@ -1415,41 +1427,38 @@ KFPOS_FN void iekf8(const double xhat[8], double z, const Cov<8, true> &P, Cov<8
             const double vx = x[2], vy = x[3], ax = x[4], ay = x[5];
             /* linearised innovations r = y - H delta = y + H dprev; the quadratic terms of qd use the final dl
              * and are added after the last row */
-            const int ixp[4] = {2, 3, 6, 7};
             const double hp0[4] = {cs, sn, -sn * vx + cs * vy, pr.px4_arm_p1 * sw - pr.px4_arm_p2 * cw};   /* :627-655 */
             const double hp1[4] = {-sn, cs, -cs * vx - sn * vy, pr.px4_arm_p1 * cw + pr.px4_arm_p2 * sw};
-            const int ix7[1] = {7}, ix6[1] = {6};
             const double one[1] = {1.0};
-            const double rp0 = ypx[0] + row_dot8(dprev, ixp, hp0), rp1 = ypx[1] + row_dot8(dprev, ixp, hp1),
+            const double rp0 = ypx[0] + row_dot8<2, 3, 6, 7>(dprev, hp0), rp1 = ypx[1] + row_dot8<2, 3, 6, 7>(dprev, hp1),
                          rp2 = ypx[2] + dprev[7];
             const bool onp = (rows & ROW_PX4) != 0;
-            seq_row8(Pout, dl, ixp, hp0, lt.px4[3], rp0, onp);
-            seq_row8(Pout, dl, ixp, hp1, lt.px4[3], rp1, onp);
-            seq_row8(Pout, dl, ix7, one, lt.px4[4], rp2, onp);
+            seq_row8<2, 3, 6, 7>(Pout, dl, hp0, lt.px4[3], rp0, onp);
+            seq_row8<2, 3, 6, 7>(Pout, dl, hp1, lt.px4[3], rp1, onp);
+            seq_row8<7>(Pout, dl, one, lt.px4[4], rp2, onp);
             /* accelerometer pair (:657-686): decorrelate with the LDL' of its 2x2 noise block (taken as
              * symmetric: c01 is used for both off-diagonal entries): row1' = row1 - (c01 / c00) row0 */
-            const int ixi[3] = {4, 5, 6};
             const double hi0[3] = {cs, sn, -sn * ax + cs * ay};
             const double hi1[3] = {-sn, cs, -cs * ax - sn * ay};
             const bool oni = (rows & ROW_IMU) != 0;
-            const double ri0 = yim[0] + row_dot8(dprev, ixi, hi0), ri1 = yim[1] + row_dot8(dprev, ixi, hi1),
+            const double ri0 = yim[0] + row_dot8<4, 5, 6>(dprev, hi0), ri1 = yim[1] + row_dot8<4, 5, 6>(dprev, hi1),
                          ri2 = yim[2] + dprev[7];
             const double lc = lt.imu[4] / lt.imu[3];
             const double hi1d[3] = {hi1[0] - lc * hi0[0], hi1[1] - lc * hi0[1], hi1[2] - lc * hi0[2]};
-            seq_row8(Pout, dl, ixi, hi0, lt.imu[3], ri0, oni);
-            seq_row8(Pout, dl, ixi, hi1d, lt.imu[6] - lc * lt.imu[4], ri1 - lc * ri0, oni);
-            seq_row8(Pout, dl, ix7, one, lt.imu[7], ri2, oni);
+            seq_row8<4, 5, 6>(Pout, dl, hi0, lt.imu[3], ri0, oni);
+            seq_row8<4, 5, 6>(Pout, dl, hi1d, lt.imu[6] - lc * lt.imu[4], ri1 - lc * ri0, oni);
+            seq_row8<7>(Pout, dl, one, lt.imu[7], ri2, oni);
             const bool onm = (rows & ROW_MAG) != 0;
             const double rm = ymag + dprev[6];
-            seq_row8(Pout, dl, ix6, one, lt.mag[1], rm, onm);
+            seq_row8<6>(Pout, dl, one, lt.mag[1], rm, onm);
             /* delta' pinv(P) delta = sum over row groups of (H dl)' R^-1 (r - H dl), at the final dl */
             qd = u0 * dl[0] + u1 * dl[1] - (m0 * dl[0] * dl[0] + 2.0 * m1 * dl[0] * dl[1] + m3 * dl[1] * dl[1]);
             if (onp) {
-                const double a0 = row_dot8(dl, ixp, hp0), a1 = row_dot8(dl, ixp, hp1), a2 = dl[7];
+                const double a0 = row_dot8<2, 3, 6, 7>(dl, hp0), a1 = row_dot8<2, 3, 6, 7>(dl, hp1), a2 = dl[7];
                 qd += a0 * (rp0 - a0) / lt.px4[3] + a1 * (rp1 - a1) / lt.px4[3] + a2 * (rp2 - a2) / lt.px4[4];
             }
             if (oni) {
-                const double a0 = row_dot8(dl, ixi, hi0), a1 = row_dot8(dl, ixi, hi1), a2 = dl[7];
+                const double a0 = row_dot8<4, 5, 6>(dl, hi0), a1 = row_dot8<4, 5, 6>(dl, hi1), a2 = dl[7];
                 const double e0 = ri0 - a0, e1 = ri1 - a1; /* a' R^-1 e, R symmetric */
                 qd += (a0 * e0 * lt.imu[6] - (a0 * e1 + a1 * e0) * lt.imu[4] + a1 * e1 * lt.imu[3]) /
                           (lt.imu[3] * lt.imu[6] - lt.imu[4] * lt.imu[4]) +
@@ -1488,7 +1497,8 @@ KFPOS_FN void cov_update8(Cov<8, true> &P, const double m[3]) {
 
 /* KalmanFilter::estimatePositionKF (KalmanFilter.cpp:224-321) for one tag and one call carrying `rows`. */
 template <bool SENSORS, class SC>
-KFPOS_FN uint32_t step_planar8(Tag8 &tg, SC &sc, const Params &pr, double dt, uint32_t rows, const Latch8 &lt) {
+KFPOS_FN uint32_t step_planar8(Tag8 &tg, SC &sc, const Params &pr, double dt, uint32_t rows, const Latch8 &lt,
+                               CovSpill8 spill = CovSpill8{nullptr, 0}) {
     const bool has_r = (rows & ROW_RANGING) != 0;
     const int n_valid = has_r ? count_used(sc, pr, 0) : 0;
     if (!pr.use_init_pos && (isnan(tg.xy[0]) || isnan(tg.xy[1]))) { /* :243-278 */
@@ -1534,10 +1544,10 @@ KFPOS_FN uint32_t step_planar8(Tag8 &tg, SC &sc, const Params &pr, double dt, ui
     }
     /* no try/catch in this filter: the reference node aborts; here the predicted covariance is kept */
     if (o.flags & ST_UPDATE_SKIPPED) return ST_UPDATE_SKIPPED;
-    if (SENSORS) {
-        Cov<8, true> Pn = tg.P;
-        iekf8<true>(xhat, tg.z, tg.P, Pn, sc, pr, rows, lt, dt, o);
-        tg.P = Pn;
+    if (SENSORS) { /* predicted covariance parked in `spill`, tg.P becomes the working copy */
+        KFPOS_UNROLL
+        for (int k = 0; k < 36; ++k) spill.base[k * spill.stride] = tg.P.a[k];
+        iekf8<true>(xhat, tg.z, spill, tg.P, sc, pr, rows, lt, dt, o);
     } else {
         iekf8<false>(xhat, tg.z, tg.P, tg.P, sc, pr, rows, lt, dt, o);
         cov_update8(tg.P, o.mlast);

@@ -51,9 +51,16 @@ struct KArgs {
     int T, A;
     double accel_noise, jolt, cost_threshold;
     int ignore_worst, top_n, use_init_pos;
+    /* planar filter configuration (kfpos_planar_config) */
+    int use_fixed_height, imu_fixed_cov_acc, imu_fixed_cov_w;
+    double px4_height, px4_arm_p1, px4_arm_p2, px4_cov_vel, px4_cov_gyro_z;
+    double imu_cov_acc, imu_cov_w, mag_offset, mag_cov;
+    double *platch;   /* [15][T] planar filter: latched PX4Flow (5), IMU (8), magnetometer (2) samples */
+    const double *sensor; /* planar sensor call: [C][T] sample of this call (C = 5 / 24 / 3 / 1) */
     /* persistent state, component-major */
     double *pos;      /* [3][T] */
-    double *vel;      /* [3][T] (9-state; always f64: the 9-state filter amplifies velocity rounding) */
+    double *vel;      /* [3][T] (9-state; always f64: the 9-state filter amplifies velocity rounding);
+                         planar filter: [4][T] = vx, vy, theta, omega */
     void *P;          /* [SZ][T] real */
     uint32_t *flags;  /* [T] */
     void *imu_acc;    /* [3][T] real, latched sample (9-state) */
@@ -97,6 +104,18 @@ __device__ inline Params make_params(const KArgs &a) {
     pr.ignore_worst = a.ignore_worst;
     pr.top_n = a.top_n;
     pr.use_init_pos = a.use_init_pos;
+    pr.use_fixed_height = a.use_fixed_height;
+    pr.imu_fixed_cov_acc = a.imu_fixed_cov_acc;
+    pr.imu_fixed_cov_w = a.imu_fixed_cov_w;
+    pr.px4_height = a.px4_height;
+    pr.px4_arm_p1 = a.px4_arm_p1;
+    pr.px4_arm_p2 = a.px4_arm_p2;
+    pr.px4_cov_vel = a.px4_cov_vel;
+    pr.px4_cov_gyro_z = a.px4_cov_gyro_z;
+    pr.imu_cov_acc = a.imu_cov_acc;
+    pr.imu_cov_w = a.imu_cov_w;
+    pr.mag_offset = a.mag_offset;
+    pr.mag_cov = a.mag_cov;
     return pr;
 }
 
@@ -396,6 +415,162 @@ __global__ __launch_bounds__(WAVE) void k_step_imu9(const KArgs a) {
     if (a.status) a.status[t] = s;
 }
 
+/* ------------------------------------------------------------------ 8-state planar step kernel */
+/* KalmanFilter (ALGORITHM_KF). a.mode: 0 = ranging epoch (carries whatever the tag has latched), 1..4 = one of
+ * the four other sensor entry points (KFPOS_SENSOR_*), which latch their sample and run an update without
+ * ranging rows. SENS = false is the ranging-only bank: no latch traffic, closed-form 2x2 update. Flags word:
+ * bit 0 started, bits 5..7 = latched PX4Flow / IMU / magnetometer. */
+constexpr int PLANAR_HAS_SHIFT = 4;
+constexpr int LATCH_ROWS = 15;
+
+template <bool SENS, typename REAL, typename MREAL, int AS>
+__global__ __launch_bounds__(WAVE) void k_step_planar(const KArgs a) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const size_t t = (size_t)blockIdx.x * WAVE + lane;
+    if (t >= (size_t)a.T) return;
+    const size_t T = a.T;
+    const uint32_t t32 = (uint32_t)t;
+    const Params pr = make_params(a);
+    const int kind = a.mode;
+    const bool has_ranging = kind == 0;
+    constexpr int NA = AS > 0 ? AS : 1;
+    if (a.n_steps == 1 && a.dt && a.dt[t] < 0.0) { /* no epoch / sample for this tag in this call */
+        if (a.status) a.status[t] = ST_SKIPPED;
+        return;
+    }
+    RawEpoch<MREAL, NA> raw;
+    if constexpr (AS > 0) {
+        if (has_ranging) fetch_epoch<MREAL, AS>(a, t, 0, raw);
+    }
+    Tag8 tg;
+    tg.xy[0] = (a.pos + 0 * T)[t32];
+    tg.xy[1] = (a.pos + 1 * T)[t32];
+    tg.z = (a.pos + 2 * T)[t32];
+    tg.vel[0] = (a.vel + 0 * T)[t32];
+    tg.vel[1] = (a.vel + 1 * T)[t32];
+    tg.ang = (a.vel + 2 * T)[t32];
+    tg.om = (a.vel + 3 * T)[t32];
+    uint32_t fl = a.flags[t];
+    Latch8 lt;
+    lt.has = SENS ? ((fl >> PLANAR_HAS_SHIFT) & (ROW_PX4 | ROW_IMU | ROW_MAG)) : 0u;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) lt.px4[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) lt.imu[k] = 0.0;
+    lt.mag[0] = lt.mag[1] = 0.0;
+    uint32_t rows = ROW_RANGING;
+    if constexpr (SENS) {
+        /* this call's sample (KalmanFilter.cpp:102-229); a PX4Flow sample of quality 0 is dropped on entry */
+        if (kind == KFPOS_SENSOR_PX4FLOW) {
+            double f[5], m[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) f[k] = (a.sensor + k * T)[t32];
+            if (!px4_sample(pr, f, m)) {
+                if (a.status) a.status[t] = ST_SKIPPED;
+                return;
+            }
+#pragma unroll
+            for (int k = 0; k < 5; ++k) { lt.px4[k] = m[k]; (a.platch + k * T)[t32] = m[k]; }
+            lt.has |= ROW_PX4;
+            rows = ROW_PX4;
+        } else if (kind == KFPOS_SENSOR_IMU) {
+            double w3[3], cw[9], la[3], ca[9];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { w3[k] = (a.sensor + k * T)[t32]; la[k] = (a.sensor + (12 + k) * T)[t32]; }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) { cw[k] = (a.sensor + (3 + k) * T)[t32]; ca[k] = (a.sensor + (15 + k) * T)[t32]; }
+            imu_sample8(pr, w3, cw, la, ca, lt.imu);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) (a.platch + (5 + k) * T)[t32] = lt.imu[k];
+            lt.has |= ROW_IMU;
+            rows = ROW_IMU;
+        } else if (kind == KFPOS_SENSOR_MAG || kind == KFPOS_SENSOR_COMPASS) {
+            if (kind == KFPOS_SENSOR_MAG)
+                lt.mag[0] = atan2((a.sensor + 1 * T)[t32], (a.sensor + 0 * T)[t32]) - pr.mag_offset; /* :188 */
+            else
+                lt.mag[0] = normalize_angle(a.sensor[t32]); /* :207 */
+            lt.mag[1] = pr.mag_cov;
+            (a.platch + 13 * T)[t32] = lt.mag[0];
+            (a.platch + 14 * T)[t32] = lt.mag[1];
+            const uint32_t before = lt.has;
+            lt.has |= ROW_MAG;
+            rows = kind == KFPOS_SENSOR_MAG ? ROW_MAG : (ROW_MAG | (before & (ROW_PX4 | ROW_IMU)));
+        } else {
+            rows = ROW_RANGING | lt.has; /* newTOAMeasurement: the latched samples ride along (:84-98) */
+        }
+        /* latched samples this call carries but did not bring itself */
+        if ((rows & ROW_PX4) && kind != KFPOS_SENSOR_PX4FLOW) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) lt.px4[k] = (a.platch + k * T)[t32];
+        }
+        if ((rows & ROW_IMU) && kind != KFPOS_SENSOR_IMU) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) lt.imu[k] = (a.platch + (5 + k) * T)[t32];
+        }
+        if ((rows & ROW_MAG) && kind == 0) {
+            lt.mag[0] = (a.platch + 13 * T)[t32];
+            lt.mag[1] = (a.platch + 14 * T)[t32];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 36; ++k) tg.P.a[k] = ldrow<REAL>(a.P, k, T, t32);
+
+    /* SENS: the predicted covariance is parked in LDS, [36][lane], behind the generic kernel's epoch scratch */
+    const CovSpill8 park{lds + ((AS == 0 && has_ranging) ? 3 * (size_t)a.A * WAVE : 0) + lane, WAVE};
+    uint32_t s = 0;
+    for (int e = 0; e < a.n_steps; ++e) { /* the state stays in registers from epoch to epoch */
+        const double dt = epoch_dt(a, t, e);
+        if constexpr (AS > 0) {
+            RegScratch<AS> sc;
+            if (has_ranging) {
+                unpack_epoch<MREAL, AS>(raw, sc);
+                if (e + 1 < a.n_steps) fetch_epoch<MREAL, AS>(a, t, e + 1, raw);
+            } else {
+#pragma unroll
+                for (int k = 0; k < AS; ++k) sc.r[k] = sc.e[k] = sc.w[k] = 0.0;
+            }
+            s = step_planar8<SENS>(tg, sc, pr, dt, rows, lt, park);
+        } else {
+            Scratch sc{nullptr, nullptr, nullptr, WAVE};
+            if (has_ranging) sc = stage_epoch_lds<MREAL>(a, lds, lane, t, e);
+            s = step_planar8<SENS>(tg, sc, pr, dt, rows, lt, park);
+        }
+        if (a.traj) { /* the pose a per-epoch caller would have read back (getPose at timeLag 0) */
+            (a.traj + ((size_t)e * 3 + 0) * T)[t32] = tg.xy[0];
+            (a.traj + ((size_t)e * 3 + 1) * T)[t32] = tg.xy[1];
+            (a.traj + ((size_t)e * 3 + 2) * T)[t32] = tg.z;
+        }
+        if constexpr (sizeof(REAL) == 4) { /* what n single-epoch launches would have kept in HBM */
+            if (e + 1 < a.n_steps) {
+#pragma unroll
+                for (int k = 0; k < 36; ++k) tg.P.a[k] = (double)(float)tg.P.a[k];
+            }
+        }
+    }
+
+    bool fin = isfinite(tg.xy[0]) & isfinite(tg.xy[1]) & isfinite(tg.z) & isfinite(tg.vel[0]) & isfinite(tg.vel[1]) &
+               isfinite(tg.ang) & isfinite(tg.om);
+    (a.pos + 0 * T)[t32] = tg.xy[0];
+    (a.pos + 1 * T)[t32] = tg.xy[1];
+    (a.pos + 2 * T)[t32] = tg.z;
+    (a.vel + 0 * T)[t32] = tg.vel[0];
+    (a.vel + 1 * T)[t32] = tg.vel[1];
+    (a.vel + 2 * T)[t32] = tg.ang;
+    (a.vel + 3 * T)[t32] = tg.om;
+#pragma unroll
+    for (int k = 0; k < 36; ++k) {
+        strow<REAL>(a.P, k, T, t32, tg.P.a[k]);
+        fin &= isfinite(tg.P.a[k]);
+    }
+    const bool waiting = !a.use_init_pos && isnan(tg.xy[0]);
+    if (!fin && !waiting) s |= ST_NONFINITE;
+    fl |= FL_STARTED;
+    if constexpr (SENS) fl |= lt.has << PLANAR_HAS_SHIFT;
+    a.flags[t] = fl;
+    if (a.status) a.status[t] = s;
+}
+
 /* ------------------------------------------------------------------ pose kernel (getPose) */
 struct PoseArgs {
     int T, model, full;
@@ -426,7 +601,7 @@ __global__ __launch_bounds__(WAVE) void k_get_pose(const PoseArgs a) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) cov[k] = NAN;
         if (a.full_P) {
-            constexpr int N = MODEL == 6 ? 6 : (MODEL == 3 ? 3 : 9);
+            constexpr int N = MODEL == 6 ? 6 : (MODEL == 3 ? 3 : (MODEL == 8 ? 8 : 9));
 #pragma unroll
             for (int i = 0; i < N; ++i) (a.full_x + i * T)[t32] = NAN;
             for (int i = 0; i < N * N; ++i) (a.full_P + (size_t)i * T)[t32] = NAN;
@@ -443,6 +618,34 @@ __global__ __launch_bounds__(WAVE) void k_get_pose(const PoseArgs a) {
             for (int i = 0; i < 3; ++i) (a.full_x + i * T)[t32] = pos[i];
 #pragma unroll
             for (int i = 0; i < 9; ++i) (a.full_P + (size_t)i * T)[t32] = cov[i];
+        }
+    } else if (MODEL == 8) { /* KalmanFilter::getPose, KalmanFilter.cpp:709-745 */
+        Tag8 tg;
+        tg.xy[0] = (a.pos_in + 0 * T)[t32];
+        tg.xy[1] = (a.pos_in + 1 * T)[t32];
+        tg.z = (a.pos_in + 2 * T)[t32];
+        tg.vel[0] = (a.vel_in + 0 * T)[t32];
+        tg.vel[1] = (a.vel_in + 1 * T)[t32];
+        tg.ang = (a.vel_in + 2 * T)[t32];
+        tg.om = (a.vel_in + 3 * T)[t32];
+#pragma unroll
+        for (int k = 0; k < 36; ++k) tg.P.a[k] = ldrow<REAL>(a.P, k, T, t32);
+        double x8[8];
+        Cov<8, true> Pp;
+        pose8(tg, ahead, a.accel_noise, a.jolt, x8, Pp);
+        pos[0] = x8[0]; pos[1] = x8[1]; pos[2] = tg.z;
+        vel[0] = x8[2]; vel[1] = x8[3]; vel[2] = 0.0;
+        /* position block of stateToPose's 6x6: eye * 0.01 with the xy block of P (:349-354) */
+        cov[0] = Pp(0, 0); cov[1] = Pp(0, 1); cov[2] = 0.0;
+        cov[3] = Pp(0, 1); cov[4] = Pp(1, 1); cov[5] = 0.0;
+        cov[6] = 0.0; cov[7] = 0.0; cov[8] = 0.01;
+        if (a.full_P) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                (a.full_x + i * T)[t32] = x8[i];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) (a.full_P + (size_t)(i * 8 + j) * T)[t32] = Pp(i, j);
+            }
         }
     } else if (MODEL == 6) {
         Tag6<SYMM> tg;
@@ -529,11 +732,17 @@ struct kfpos_handle {
     double *d_dt = nullptr, *d_out = nullptr; /* d_out: [15][T] doubles for pose results */
     uint32_t *d_status = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    /* planar filter */
+    kfpos_planar_config planar = {};
+    bool planar_sensors = false; /* a PX4Flow / IMU / magnetometer / compass sample has been fed: latches are live */
+    double *d_latch = nullptr;   /* [15][T] */
+    double *d_sensor = nullptr;  /* [24][T] staging of one sensor sample */
 };
 
 namespace {
 
 size_t lds_bytes(const kfpos_handle *h) { return (size_t)3 * h->cfg.max_anchors * WAVE * sizeof(double); }
+size_t park_bytes() { return (size_t)36 * WAVE * sizeof(double); } /* planar filter with sensor rows: CovSpill8 */
 
 void fill_args(const kfpos_handle *h, KArgs &a) {
     std::memcpy(a.anchors, h->anchors, sizeof(a.anchors));
@@ -545,6 +754,20 @@ void fill_args(const kfpos_handle *h, KArgs &a) {
     a.ignore_worst = h->cfg.ignore_worst;
     a.top_n = h->cfg.top_n;
     a.use_init_pos = h->cfg.use_init_pos;
+    a.use_fixed_height = h->planar.use_fixed_height;
+    a.imu_fixed_cov_acc = h->planar.imu_use_fixed_cov_acc;
+    a.imu_fixed_cov_w = h->planar.imu_use_fixed_cov_ang_vel_z;
+    a.px4_height = h->planar.px4_height;
+    a.px4_arm_p1 = h->planar.px4_arm_p1;
+    a.px4_arm_p2 = h->planar.px4_arm_p2;
+    a.px4_cov_vel = h->planar.px4_cov_velocity;
+    a.px4_cov_gyro_z = h->planar.px4_cov_gyro_z;
+    a.imu_cov_acc = h->planar.imu_cov_acc;
+    a.imu_cov_w = h->planar.imu_cov_ang_vel_z;
+    a.mag_offset = h->planar.mag_angle_offset;
+    a.mag_cov = h->planar.mag_cov;
+    a.platch = h->d_latch;
+    a.sensor = nullptr;
     a.pos = h->d_pos;
     a.vel = h->d_vel;
     a.P = h->d_P;
@@ -591,8 +814,25 @@ step_kernel_t ml_kernel(int as) {
     return k_step_ml<REAL, MREAL, 0>;
 }
 
-step_kernel_t step_kernel(const kfpos_handle *h) {
-    const int st = h->cfg.storage, as = h->force_generic ? 0 : static_anchors(h);
+/* With sensor rows the register-resident epoch of the 8-anchor specialisation no longer fits (measured: 212-244
+ * bytes/lane of scratch), so those banks always run the LDS-staged kernel. */
+template <bool SENS, typename REAL, typename MREAL>
+step_kernel_t planar_kernel(int as) {
+    if constexpr (!SENS) {
+        if (as == 8) return k_step_planar<false, REAL, MREAL, 8>;
+    }
+    return k_step_planar<SENS, REAL, MREAL, 0>;
+}
+template <bool SENS>
+step_kernel_t planar_kernel_st(int st, int as) {
+    return st == KFPOS_STORE_F32 ? planar_kernel<SENS, float, float>(as)
+         : st == KFPOS_STORE_MIXED ? planar_kernel<SENS, double, float>(as) : planar_kernel<SENS, double, double>(as);
+}
+
+step_kernel_t step_kernel(const kfpos_handle *h, bool sensor_call = false) {
+    const int st = h->cfg.storage, as = (h->force_generic || sensor_call) ? 0 : static_anchors(h);
+    if (h->cfg.model == KFPOS_MODEL_PLANAR)
+        return (h->planar_sensors || sensor_call) ? planar_kernel_st<true>(st, as) : planar_kernel_st<false>(st, as);
     if (h->cfg.model == KFPOS_MODEL_ML)
         return st == KFPOS_STORE_F32 ? ml_kernel<float, float>(as)
              : st == KFPOS_STORE_MIXED ? ml_kernel<double, float>(as) : ml_kernel<double, double>(as);
@@ -611,9 +851,12 @@ step_kernel_t step_kernel(const kfpos_handle *h) {
 
 int launch_step(kfpos_handle *h, const KArgs &a, hipStream_t s) {
     const int blocks = (h->cfg.n_tags + WAVE - 1) / WAVE;
-    const bool generic = h->force_generic || static_anchors(h) == 0;
-    const size_t lds = (a.mode == MODE_IMU_ONLY || !generic) ? 0 : lds_bytes(h);
-    hipLaunchKernelGGL(step_kernel(h), dim3(blocks), dim3(WAVE), lds, s, a);
+    const bool generic = h->force_generic || static_anchors(h) == 0 ||
+                         (h->cfg.model == KFPOS_MODEL_PLANAR && h->planar_sensors);
+    const bool planar_sensor = h->cfg.model == KFPOS_MODEL_PLANAR && a.mode != 0;
+    size_t lds = (a.mode == MODE_IMU_ONLY || planar_sensor || !generic) ? 0 : lds_bytes(h);
+    if (h->cfg.model == KFPOS_MODEL_PLANAR && (h->planar_sensors || planar_sensor)) lds += park_bytes();
+    hipLaunchKernelGGL(step_kernel(h, planar_sensor), dim3(blocks), dim3(WAVE), lds, s, a);
     HIPCHK(hipGetLastError());
     h->stepped = true;
     return KFPOS_OK;
@@ -687,13 +930,15 @@ int kfpos_version(void) { return KFPOS_VERSION; }
 int kfpos_create(const kfpos_config *cfg, kfpos_handle **out) {
     if (!cfg || !out) return KFPOS_ERR_ARG;
     *out = nullptr;
-    if (cfg->model != KFPOS_MODEL_TOA && cfg->model != KFPOS_MODEL_TOA_IMU && cfg->model != KFPOS_MODEL_ML)
+    if (cfg->model != KFPOS_MODEL_TOA && cfg->model != KFPOS_MODEL_TOA_IMU && cfg->model != KFPOS_MODEL_ML &&
+        cfg->model != KFPOS_MODEL_PLANAR)
         return KFPOS_ERR_ARG;
     if (cfg->storage != KFPOS_STORE_F64 && cfg->storage != KFPOS_STORE_F32 && cfg->storage != KFPOS_STORE_MIXED)
         return KFPOS_ERR_ARG;
     if (cfg->n_tags < 1 || cfg->max_anchors < 1 || cfg->max_anchors > KFPOS_MAX_ANCHORS) return KFPOS_ERR_ARG;
     if (cfg->top_n < 0 || (cfg->model == KFPOS_MODEL_TOA_IMU && (cfg->top_n || cfg->ignore_worst)) ||
-        (cfg->model == KFPOS_MODEL_ML && cfg->ignore_worst))
+        (cfg->model == KFPOS_MODEL_ML && cfg->ignore_worst) ||
+        (cfg->model == KFPOS_MODEL_PLANAR && (cfg->top_n || cfg->ignore_worst)))
         return KFPOS_ERR_ARG; /* both heuristics exist for the 6-state filter only */
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) {
@@ -704,7 +949,7 @@ int kfpos_create(const kfpos_config *cfg, kfpos_handle **out) {
     kfpos_handle *h = new (std::nothrow) kfpos_handle();
     if (!h) return KFPOS_ERR_ARG;
     h->cfg = *cfg;
-    h->n = cfg->model == KFPOS_MODEL_TOA_IMU ? 9 : (cfg->model == KFPOS_MODEL_ML ? 3 : 6);
+    h->n = cfg->model == KFPOS_MODEL_TOA_IMU ? 9 : (cfg->model == KFPOS_MODEL_ML ? 3 : (cfg->model == KFPOS_MODEL_PLANAR ? 8 : 6));
     h->full = (cfg->model == KFPOS_MODEL_TOA && !cfg->use_init_pos) ? 1 : 0;
     h->psz = h->full ? h->n * h->n : h->n * (h->n + 1) / 2;
     h->rsz = cfg->storage == KFPOS_STORE_F32 ? 4 : 8;
@@ -735,6 +980,11 @@ int kfpos_create(const kfpos_config *cfg, kfpos_handle **out) {
     ALLOC(h->d_P, h->psz * T * r);
     ALLOC(h->d_flags, T * sizeof(uint32_t));
     if (h->n == 3) ALLOC(h->d_vel, 3 * T * sizeof(double)); /* ALGORITHM_ML: the solver's per-tag seed */
+    if (h->n == 8) {
+        ALLOC(h->d_vel, 4 * T * sizeof(double)); /* vx, vy, theta, omega */
+        ALLOC(h->d_latch, LATCH_ROWS * T * sizeof(double));
+        ALLOC(h->d_sensor, 24 * T * sizeof(double));
+    }
     if (h->n == 9) {
         ALLOC(h->d_vel, 3 * T * sizeof(double));
         ALLOC(h->d_imu_acc, 3 * T * m);
@@ -753,9 +1003,15 @@ int kfpos_create(const kfpos_config *cfg, kfpos_handle **out) {
         kfpos_destroy(h);
         return KFPOS_ERR_HIP;
     }
-    if (lds_bytes(h) > 64 * 1024) {
+    if (lds_bytes(h) + (cfg->model == KFPOS_MODEL_PLANAR ? park_bytes() : 0) > 64 * 1024) {
         hipError_t e_ = hipFuncSetAttribute((const void *)step_kernel(h),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(h));
+        if (e_ == hipSuccess && cfg->model == KFPOS_MODEL_PLANAR) { /* the instantiation ranging epochs switch to */
+            h->planar_sensors = true;
+            e_ = hipFuncSetAttribute((const void *)step_kernel(h), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)(lds_bytes(h) + park_bytes()));
+            h->planar_sensors = false;
+        }
         if (e_ != hipSuccess) {
             g_err = std::string("hipFuncSetAttribute: ") + hipGetErrorString(e_);
             kfpos_destroy(h);
@@ -765,7 +1021,10 @@ int kfpos_create(const kfpos_config *cfg, kfpos_handle **out) {
     /* initial position: fixed start (P0 = 0) or NaN until the ML initialisation */
     std::vector<double> p0(3 * T);
     for (size_t t = 0; t < T; ++t)
-        for (int k = 0; k < 3; ++k) p0[(size_t)k * T + t] = cfg->use_init_pos ? cfg->init_pos[k] : NAN;
+        for (int k = 0; k < 3; ++k) {
+            p0[(size_t)k * T + t] = cfg->use_init_pos ? cfg->init_pos[k] : NAN;
+            if (h->n == 8 && k == 2) p0[(size_t)k * T + t] = 0.0; /* mUWBtagZ: kfpos_set_planar, not initialPosition.z */
+        }
     if (h->n == 3 && hipMemcpy(h->d_vel, p0.data(), p0.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
         g_err = "hipMemcpy(ml seed) failed";
         kfpos_destroy(h);
@@ -783,7 +1042,7 @@ int kfpos_create(const kfpos_config *cfg, kfpos_handle **out) {
 int kfpos_destroy(kfpos_handle *h) {
     if (!h) return KFPOS_ERR_ARG;
     void *ptrs[] = {h->d_pos, h->d_vel, h->d_P, h->d_imu_acc, h->d_imu_cov, h->d_flags, h->d_ranges,
-                    h->d_err, h->d_accel, h->d_cov, h->d_dt, h->d_out, h->d_status};
+                    h->d_err, h->d_accel, h->d_cov, h->d_dt, h->d_out, h->d_status, h->d_latch, h->d_sensor};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -811,7 +1070,26 @@ int kfpos_set_init_positions(kfpos_handle *h, const double *xyz) {
         const int rc = stage_in(h, h->d_vel, xyz, 3, sizeof(double));
         if (rc) return rc;
     }
-    return stage_in(h, h->d_pos, xyz, 3, sizeof(double));
+    const int rc = stage_in(h, h->d_pos, xyz, 3, sizeof(double));
+    if (rc == KFPOS_OK && h->n == 8) { /* the filter works at mUWBtagZ, whatever initialPosition.z says */
+        std::vector<double> z(h->cfg.n_tags, h->planar.fixed_height);
+        HIPCHK(hipMemcpy(h->d_pos + 2 * (size_t)h->cfg.n_tags, z.data(), z.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    return rc;
+}
+
+int kfpos_set_planar(kfpos_handle *h, const kfpos_planar_config *cfg) {
+    if (!h || !cfg) return KFPOS_ERR_ARG;
+    if (h->cfg.model != KFPOS_MODEL_PLANAR) return KFPOS_ERR_MODEL;
+    if (h->stepped) return KFPOS_ERR_STATE;
+    h->planar = *cfg;
+    /* mUWBtagZ and mAngle of every tag: pos row 2, vel row 2 (angular speed, row 3, stays 0) */
+    const size_t T = h->cfg.n_tags;
+    std::vector<double> v(T, cfg->fixed_height);
+    HIPCHK(hipMemcpy(h->d_pos + 2 * T, v.data(), T * sizeof(double), hipMemcpyHostToDevice));
+    v.assign(T, cfg->init_angle);
+    HIPCHK(hipMemcpy(h->d_vel + 2 * T, v.data(), T * sizeof(double), hipMemcpyHostToDevice));
+    return KFPOS_OK;
 }
 
 int kfpos_real_size(const kfpos_handle *h) { return h ? h->msz : 0; }
@@ -847,6 +1125,35 @@ int kfpos_step_imu_dev(kfpos_handle *h, const void *accel, const void *cov, cons
     a.mode = MODE_IMU_ONLY;
     a.latch = 1;
     return launch_step(h, a, (hipStream_t)stream);
+}
+
+static int sensor_width(int32_t kind) {
+    switch (kind) {
+    case KFPOS_SENSOR_PX4FLOW: return 5;
+    case KFPOS_SENSOR_IMU: return 24;
+    case KFPOS_SENSOR_MAG: return 3;
+    case KFPOS_SENSOR_COMPASS: return 1;
+    default: return 0;
+    }
+}
+
+int kfpos_step_sensor_dev(kfpos_handle *h, int32_t kind, const double *data, const double *dt, double dt_shared,
+                          uint32_t *status, void *stream) {
+    if (!h || !data || sensor_width(kind) == 0) return KFPOS_ERR_ARG;
+    if (h->cfg.model != KFPOS_MODEL_PLANAR) { /* the empty virtuals of PositionEstimationAlgorithm.h:26-35 */
+        if (status) HIPCHK(hipMemsetAsync(status, 0, sizeof(uint32_t) * h->cfg.n_tags, (hipStream_t)stream));
+        return KFPOS_OK;
+    }
+    KArgs a;
+    fill_args(h, a);
+    a.sensor = data;
+    a.dt = dt;
+    a.dt_shared = dt_shared;
+    a.status = status;
+    a.mode = kind;
+    const int rc = launch_step(h, a, (hipStream_t)stream);
+    h->planar_sensors = true; /* ranging epochs now carry the latched samples */
+    return rc;
 }
 
 int kfpos_step_toa_imu_dev(kfpos_handle *h, const int32_t *range_mm, const void *err_est, const void *accel,
@@ -932,7 +1239,10 @@ static int launch_pose(kfpos_handle *h, double dt_ahead, const double *dt_each, 
     const int blocks = (a.T + WAVE - 1) / WAVE;
     const bool f32 = h->cfg.storage == KFPOS_STORE_F32;
     hipStream_t s = (hipStream_t)stream;
-    if (h->cfg.model == KFPOS_MODEL_ML) {
+    if (h->cfg.model == KFPOS_MODEL_PLANAR) {
+        if (f32) hipLaunchKernelGGL((k_get_pose<8, true, float>), dim3(blocks), dim3(WAVE), 0, s, a);
+        else hipLaunchKernelGGL((k_get_pose<8, true, double>), dim3(blocks), dim3(WAVE), 0, s, a);
+    } else if (h->cfg.model == KFPOS_MODEL_ML) {
         if (f32) hipLaunchKernelGGL((k_get_pose<3, true, float>), dim3(blocks), dim3(WAVE), 0, s, a);
         else hipLaunchKernelGGL((k_get_pose<3, true, double>), dim3(blocks), dim3(WAVE), 0, s, a);
     } else if (h->cfg.model == KFPOS_MODEL_TOA_IMU) {
@@ -984,6 +1294,31 @@ int kfpos_step_imu(kfpos_handle *h, const void *accel, const void *cov, const do
     if ((rc = stage_in(h, h->d_cov, cov, 9, h->msz))) return rc;
     if ((rc = kfpos_step_imu_dev(h, h->d_accel, h->d_cov, d_dt, shared, h->d_status, nullptr))) return rc;
     return fetch_status(h, status);
+}
+
+int kfpos_step_sensor(kfpos_handle *h, int32_t kind, const double *data, const double *dt, int32_t dt_len,
+                      uint32_t *status) {
+    const int C = sensor_width(kind);
+    if (!h || !data || C == 0) return KFPOS_ERR_ARG;
+    if (h->cfg.model != KFPOS_MODEL_PLANAR) {
+        if (status) std::memset(status, 0, sizeof(uint32_t) * h->cfg.n_tags);
+        return KFPOS_OK;
+    }
+    const double *d_dt;
+    double shared;
+    int rc = stage_dt(h, dt, dt_len, &d_dt, &shared);
+    if (rc) return rc;
+    if ((rc = stage_in(h, h->d_sensor, data, C, sizeof(double)))) return rc;
+    if ((rc = kfpos_step_sensor_dev(h, kind, h->d_sensor, d_dt, shared, h->d_status, nullptr))) return rc;
+    return fetch_status(h, status);
+}
+
+int kfpos_get_height(kfpos_handle *h, double *z) {
+    if (!h || !z) return KFPOS_ERR_ARG;
+    if (h->cfg.model != KFPOS_MODEL_PLANAR) return KFPOS_ERR_MODEL;
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(z, h->d_pos + 2 * (size_t)h->cfg.n_tags, sizeof(double) * h->cfg.n_tags, hipMemcpyDeviceToHost));
+    return KFPOS_OK;
 }
 
 int kfpos_step_toa_imu(kfpos_handle *h, const int32_t *range_mm, const void *err_est, const void *accel,
@@ -1074,12 +1409,21 @@ int kfpos_get_state(kfpos_handle *h, double *x, double *P, uint32_t *flags) {
         std::vector<double> pos(3 * T);
         HIPCHK(hipMemcpy(pos.data(), h->d_pos, pos.size() * sizeof(double), hipMemcpyDeviceToHost));
         std::vector<double> vel;
-        if (n == 9) {
-            vel.resize(3 * T);
+        if (n == 9 || n == 8) {
+            vel.resize((n == 8 ? 4 : 3) * T);
             HIPCHK(hipMemcpy(vel.data(), h->d_vel, vel.size() * sizeof(double), hipMemcpyDeviceToHost));
         }
         for (size_t t = 0; t < T; ++t) {
             for (int k = 0; k < n; ++k) x[t * n + k] = 0.0;
+            if (n == 8) { /* [x y vx vy 0 0 theta omega]; the height: kfpos_get_height */
+                x[t * 8 + 0] = pos[t];
+                x[t * 8 + 1] = pos[T + t];
+                x[t * 8 + 2] = vel[t];
+                x[t * 8 + 3] = vel[T + t];
+                x[t * 8 + 6] = vel[2 * T + t];
+                x[t * 8 + 7] = vel[3 * T + t];
+                continue;
+            }
             for (int k = 0; k < 3; ++k) {
                 x[t * n + k] = pos[(size_t)k * T + t];
                 if (n == 9) x[t * n + 3 + k] = vel[(size_t)k * T + t];
@@ -1106,7 +1450,19 @@ int kfpos_set_state(kfpos_handle *h, const double *x, const double *P, const uin
     HIPCHK(hipDeviceSynchronize());
     const size_t T = h->cfg.n_tags;
     const int n = h->n;
-    if (x) {
+    if (x && n == 8) { /* the height row of d_pos is kept */
+        std::vector<double> xy(2 * T), vel(4 * T);
+        for (size_t t = 0; t < T; ++t) {
+            xy[t] = x[t * 8 + 0];
+            xy[T + t] = x[t * 8 + 1];
+            vel[t] = x[t * 8 + 2];
+            vel[T + t] = x[t * 8 + 3];
+            vel[2 * T + t] = x[t * 8 + 6];
+            vel[3 * T + t] = x[t * 8 + 7];
+        }
+        HIPCHK(hipMemcpy(h->d_pos, xy.data(), xy.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d_vel, vel.data(), vel.size() * sizeof(double), hipMemcpyHostToDevice));
+    } else if (x) {
         std::vector<double> pos(3 * T);
         std::vector<double> vel(n == 9 ? 3 * T : 0);
         for (size_t t = 0; t < T; ++t)
@@ -1129,7 +1485,11 @@ int kfpos_set_state(kfpos_handle *h, const double *x, const double *P, const uin
                 }
         HIPCHK(hipMemcpy(h->d_P, buf.data(), buf.size(), hipMemcpyHostToDevice));
     }
-    if (flags) HIPCHK(hipMemcpy(h->d_flags, flags, sizeof(uint32_t) * T, hipMemcpyHostToDevice));
+    if (flags) {
+        HIPCHK(hipMemcpy(h->d_flags, flags, sizeof(uint32_t) * T, hipMemcpyHostToDevice));
+        if (n == 8) /* restored latch bits: ranging epochs must run the instantiation that honours them */
+            for (size_t t = 0; t < T; ++t) h->planar_sensors = h->planar_sensors || ((flags[t] >> PLANAR_HAS_SHIFT) != 0);
+    }
     h->stepped = true;
     return KFPOS_OK;
 }

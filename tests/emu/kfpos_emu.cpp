@@ -135,7 +135,8 @@ static uint32_t step_static(kfe_bank *b, int t, const int32_t *mm, const double 
     }
     if (b->model == 3) {
         const uint32_t rows = ROW_RANGING | b->l8[t].has;
-        return b->sensors ? step_planar8<true>(b->t8[t], sc, b->pr, lag, rows, b->l8[t])
+        double park[36];
+        return b->sensors ? step_planar8<true>(b->t8[t], sc, b->pr, lag, rows, b->l8[t], CovSpill8{park, 1})
                           : step_planar8<false>(b->t8[t], sc, b->pr, lag, rows, b->l8[t]);
     }
     if (b->model == 2) return step_ml(&b->ml_pos[3 * t], &b->ml_cov[6 * t], sc, b->pr, &b->ml_seed[3 * t]);
@@ -166,7 +167,8 @@ void kfe_step_toa(kfe_bank *b, const int32_t *range_mm, const double *err_est, c
             fill_scratch(b, mm, err, buf, sc);
             if (b->model == 3) {
                 const uint32_t rows = ROW_RANGING | b->l8[t].has;
-                st = b->sensors ? step_planar8<true>(b->t8[t], sc, b->pr, lag, rows, b->l8[t])
+                double park[36];
+                st = b->sensors ? step_planar8<true>(b->t8[t], sc, b->pr, lag, rows, b->l8[t], CovSpill8{park, 1})
                                 : step_planar8<false>(b->t8[t], sc, b->pr, lag, rows, b->l8[t]);
             } else if (b->model == 2) st = step_ml(&b->ml_pos[3 * t], &b->ml_cov[6 * t], sc, b->pr, &b->ml_seed[3 * t]);
             else if (b->model == 0 && !b->full) st = step_toa6(b->t6s[t], sc, b->pr, lag);
@@ -239,7 +241,8 @@ void kfe_planar_sensor(kfe_bank *b, int kind, const double *data, const double *
             lt.has |= ROW_MAG;
             rows = ROW_MAG | (lt.has & (ROW_PX4 | ROW_IMU));
         }
-        const uint32_t st = step_planar8<true>(b->t8[t], sc, b->pr, lag, rows, lt);
+        double park[36];
+        const uint32_t st = step_planar8<true>(b->t8[t], sc, b->pr, lag, rows, lt, CovSpill8{park, 1});
         b->flags[t] |= FL_STARTED;
         if (status) status[t] = st;
     }

@@ -148,3 +148,30 @@ def run_trace(impls, w, S, sensors=(), edge=True, collect=None):
         if collect:
             collect(s, impls)
     return out
+
+
+class PlanarGpu:
+    """The product path: libkfpos_hip.so through the C ABI (host-buffer entry points)."""
+
+    def __init__(self, w, cfg, init, accel_noise=0.5, jolt=0.5, storage=0, generic=False):
+        import os
+        from roskfpos_amd import capi
+        old = os.environ.get("KFPOS_GENERIC_KERNEL")
+        if generic:
+            os.environ["KFPOS_GENERIC_KERNEL"] = "1"  # read at kfpos_create
+        try:
+            self.b = capi.KfposBank(capi.MODEL_PLANAR, w.n_tags, w.anchors, storage=storage, accel_noise=accel_noise,
+                                    jolt=jolt, init_pos=init, planar=cfg)
+        finally:
+            if generic:
+                if old is None:
+                    del os.environ["KFPOS_GENERIC_KERNEL"]
+                else:
+                    os.environ["KFPOS_GENERIC_KERNEL"] = old
+        for name in ("step_toa", "step_px4flow", "step_planar_imu", "step_mag", "step_compass", "get_height",
+                     "get_pose"):
+            setattr(self, name, getattr(self.b, name))
+
+    def get_state(self):
+        x, P, _ = self.b.get_state()
+        return x, P

@@ -1,0 +1,144 @@
+"""8-state planar filter (KFPOS_MODEL_PLANAR) on the GPU, through the C ABI, against the CPU oracle."""
+import numpy as np
+import pytest
+
+from planar import CFG, PlanarGpu, PlanarOracle, run_trace
+from roskfpos_amd.synth import Workload
+
+pytestmark = pytest.mark.gpu
+ALL = ("imu", "px4", "mag", "compass")
+
+
+def _compare(w, cfg, init, sensors, S, gpu_kwargs, atol_x=1e-9, rtol_P=1e-6, same_status=True):
+    orc = PlanarOracle(w, cfg, init)
+    gpu = PlanarGpu(w, cfg, init, **gpu_kwargs)
+    st_o, st_g = run_trace([orc, gpu], w, S, sensors)
+    xo, Po = orc.get_state()
+    xg, Pg = gpu.get_state()
+    assert np.all(np.isfinite(xo))
+    np.testing.assert_allclose(xg, xo, rtol=0, atol=atol_x)
+    np.testing.assert_allclose(Pg, Po, rtol=rtol_P, atol=1e-12 if rtol_P < 1e-5 else 1e-7)
+    np.testing.assert_allclose(gpu.get_height(), orc.get_height(), rtol=0, atol=atol_x)
+    if same_status:
+        bad = [(k, np.flatnonzero(a != b)[:4]) for k, (a, b) in enumerate(zip(st_o, st_g)) if not np.array_equal(a, b)]
+        assert not bad, bad[:3]
+    return orc, gpu
+
+
+@pytest.mark.parametrize("fixed_init", [True, False])
+@pytest.mark.parametrize("fixed_height", [1, 0])
+@pytest.mark.parametrize("generic", [False, True])
+def test_ranging_only(fixed_init, fixed_height, generic):
+    w = Workload(200, 8)  # 3 full wavefronts + a partial one
+    cfg = dict(CFG, use_fixed_height=fixed_height)
+    _compare(w, cfg, w.init_positions() if fixed_init else None, (), 60, dict(generic=generic))
+
+
+@pytest.mark.parametrize("sensors", [("imu",), ("px4",), ("mag",), ("compass",), ALL])
+def test_sensor_rows(sensors):
+    w = Workload(150, 8)
+    _compare(w, CFG, w.init_positions(), sensors, 60, {})
+
+
+def test_all_sensors_ml_init_free_height():
+    w = Workload(100, 8)
+    _compare(w, dict(CFG, use_fixed_height=0), None, ALL, 50, {})
+
+
+@pytest.mark.parametrize("A", [5, 12, 64])
+def test_other_anchor_counts(A):
+    w = Workload(70, A)
+    _compare(w, CFG, w.init_positions(), ALL, 30, {})
+
+
+@pytest.mark.parametrize("storage,atol", [(2, 1e-9), (1, 2e-6)])
+def test_compact_storage(storage, atol):
+    """MIXED keeps the filter state exact (inputs here are float-representable or rounded identically is NOT
+    guaranteed, hence the oracle is fed the float-rounded errorEstimation); F32 rounds P between epochs."""
+    w = Workload(128, 8)
+    orc = PlanarOracle(w, CFG, w.init_positions())
+    gpu = PlanarGpu(w, CFG, w.init_positions(), storage=storage)
+    err32 = w.err_est(np.float32).astype(np.float64)
+    for s in range(60):
+        r = w.ranges_mm(s)
+        orc.step_toa(r, err32, w.dt_of(s))
+        gpu.step_toa(r, err32, w.dt_of(s))
+    xo, _ = orc.get_state()
+    xg, _ = gpu.get_state()
+    rms = np.sqrt(((xg[:, :2] - xo[:, :2]) ** 2).sum(1).mean())
+    assert rms <= atol, rms
+
+
+def test_pose_predicted_and_skips():
+    w = Workload(96, 8)
+    orc, gpu = _compare(w, CFG, w.init_positions(), ("imu", "mag"), 20, {})
+    po, co, vo, _ = orc.get_pose(0.03)
+    pg, cg, vg, st = gpu.get_pose(0.03)
+    assert np.all(st == 0)
+    np.testing.assert_allclose(pg, po, atol=1e-10)
+    np.testing.assert_allclose(vg, vo, atol=1e-10)
+    np.testing.assert_allclose(cg, co, rtol=1e-7, atol=1e-13)
+    # the whole predicted state / covariance the adaptor's stateToPose reads
+    import numpy_oracle as npo
+    x, P = gpu.get_state()
+    xp, Pp, _ = gpu.b.get_predicted(0.03)
+    F, Q = npo.planar_F(0.03), npo.planar_Q(0.03, 0.5, 0.5)
+    for t in range(0, 96, 7):
+        pr = F @ x[t]
+        pr[6] = npo.normalize_angle(pr[6])
+        np.testing.assert_allclose(xp[t], pr, atol=1e-12)
+        np.testing.assert_allclose(Pp[t], F @ P[t] @ F.T + Q, rtol=1e-10, atol=1e-15)
+    # dt < 0 with per-tag dt: those tags are left untouched, by ranging epochs and by sensor calls alike
+    dt = np.full(96, 0.05)
+    dt[::3] = -1.0
+    before, _ = gpu.get_state()
+    st = gpu.step_toa(w.ranges_mm(21), w.err_est(), dt)
+    st2 = gpu.step_compass(w.compass(21), dt)
+    after, _ = gpu.get_state()
+    assert np.all(st[::3] == 64) and np.all(st2[::3] == 64)
+    np.testing.assert_array_equal(after[::3], before[::3])
+    assert np.all(after[1::3, :2] != before[1::3, :2])
+
+
+def test_not_started_and_model_errors():
+    from roskfpos_amd import capi
+    w = Workload(64, 8)
+    gpu = PlanarGpu(w, CFG, None)
+    pos, cov, vel, st = gpu.get_pose(0.0)
+    assert np.all(st == capi.ST_NOT_STARTED) and np.all(np.isnan(pos))
+    # a sensor sample before the ML initialisation starts the clock but cannot initialise (KalmanFilter.cpp:249)
+    st = gpu.step_compass(w.compass(0), 0.1)
+    assert np.all(st == 0)
+    x, _ = gpu.get_state()
+    assert np.all(np.isnan(x[:, :2]))
+    # the other models ignore sensor samples like the reference's empty virtuals
+    other = capi.KfposBank(capi.MODEL_TOA, 64, w.anchors, init_pos=w.init_positions())
+    assert np.all(other.step_sensor(capi.SENSOR_COMPASS, w.compass(0), 0.1) == 0)
+    with pytest.raises(capi.KfposError):
+        other.get_height()
+
+
+def test_fused_trace_equals_per_epoch_launches():
+    import torch
+    from roskfpos_amd import capi
+    T, A, S = 256, 8, 40
+    w = Workload(T, A)
+    seq = PlanarGpu(w, CFG, w.init_positions())
+    rep = PlanarGpu(w, CFG, w.init_positions())
+    r = np.stack([w.ranges_mm(s) for s in range(S)])
+    dt = np.array([w.dt_of(s) for s in range(S)])
+    for s in range(S):
+        seq.step_toa(r[s], w.err_est(), dt[s])
+    dev = "cuda:0"
+    rt = torch.from_numpy(np.ascontiguousarray(r.transpose(0, 2, 1))).to(dev)
+    et = torch.from_numpy(np.ascontiguousarray(w.err_est().T)).to(dev)
+    traj = torch.zeros(S, 3, T, dtype=torch.float64, device=dev)
+    rep.b.run_trace_dev(S, rt, A * T, et, 0, dt, trajectory=traj, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    xs, Ps = seq.get_state()
+    xr, Pr = rep.get_state()
+    np.testing.assert_array_equal(xr, xs)
+    np.testing.assert_array_equal(Pr, Ps)
+    last = traj[-1].cpu().numpy().T
+    np.testing.assert_array_equal(last[:, :2], xs[:, :2])
+    np.testing.assert_array_equal(last[:, 2], seq.get_height())
