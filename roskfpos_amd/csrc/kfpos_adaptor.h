@@ -6,6 +6,7 @@
  *   PositionEstimationAlgorithm   src/kfpos/algorithms/PositionEstimationAlgorithm.h:8-37
  *   KalmanFilterTOA               src/kfpos/algorithms/KalmanFilterTOA.h:18-54
  *   KalmanFilterTOAIMU            src/kfpos/algorithms/KalmanFilterTOAIMU.h:16-78
+ *   KalmanFilter                  src/kfpos/algorithms/KalmanFilter.h:29-133 (8-state planar filter, ALGORITHM_KF)
  *   Vector3 / VectorDim3 / Beacon src/kfpos/algorithms/sensor_types.h:7-25
  * Differences, all at the type level: Vector3::covarianceMatrix is a plain row-major array with its
  * dimension (the reference embeds an arma::mat); the estimator reads time from an injectable clock
@@ -17,13 +18,18 @@
 #ifndef KFPOS_ADAPTOR_H
 #define KFPOS_ADAPTOR_H
 
+#include <cctype>
 #include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <cstdlib>
+#include <fstream>
 #include <functional>
+#include <sstream>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "kfpos.h"
@@ -35,7 +41,7 @@ struct Vector3 { /* sensor_types.h:7-13 */
     double rotX = 0, rotY = 0, rotZ = 0, rotW = 0;
     double linearSpeedX = 0, linearSpeedY = 0, linearSpeedZ = 0;
     double angularSpeedX = 0, angularSpeedY = 0, angularSpeedZ = 0;
-    int covarianceDim = 0;             /* 6 (TOA) or 9 (TOA+IMU): stateToPose */
+    int covarianceDim = 0;             /* 6 (TOA, planar) or 9 (TOA+IMU): stateToPose */
     double covarianceMatrix[81] = {0}; /* row-major covarianceDim x covarianceDim */
 };
 struct VectorDim3 { double x, y, z; };  /* sensor_types.h:15-17 */
@@ -206,6 +212,203 @@ protected:
         }
         pose.covarianceMatrix[7 * 9 + 7] = P[8 * 9 + 8];
     }
+};
+
+/* ---- ALGORITHM_KF: the 8-state planar filter ---- */
+
+/* The reference reads its configuration from five ROS parameters whose VALUES are XML documents
+ * (node_pos.cpp:111: "configPos", "configPX4Flow", "configUWB", "configIMU", "configMAG"; the launch files fill
+ * them with <param textfile=.../>). A ParamSource stands for NodeHandle::getParam(name, content). */
+using ParamSource = std::function<bool(const std::string &name, std::string &content)>;
+
+/* ParamSource over a name -> file path table (what <param name=... textfile=.../> does) */
+inline ParamSource fileParamSource(std::vector<std::pair<std::string, std::string>> table) {
+    return [table](const std::string &name, std::string &content) {
+        for (const auto &kv : table)
+            if (kv.first == name) {
+                std::ifstream f(kv.second);
+                if (!f) return false;
+                std::stringstream ss;
+                ss << f.rdbuf();
+                content = ss.str();
+                return true;
+            }
+        return false;
+    };
+}
+
+/* The slice of boost::property_tree's XML reader the reference relies on (KalmanFilter.cpp:763-842): children of
+ * <config> named `element`, attribute lookup with a default, comments skipped, later elements overriding
+ * earlier ones. Returns false when there is no <config> root (property_tree would throw -> init() false). */
+class XmlAttributes {
+public:
+    bool parse(const std::string &xml) {
+        text_.clear();
+        for (size_t i = 0; i < xml.size();) { /* drop <!-- ... --> */
+            if (xml.compare(i, 4, "<!--") == 0) {
+                const size_t e = xml.find("-->", i + 4);
+                if (e == std::string::npos) break;
+                i = e + 3;
+            } else {
+                text_ += xml[i++];
+            }
+        }
+        return text_.find("<config") != std::string::npos;
+    }
+    /* value of `attr` in the last <element .../>, or false if absent */
+    bool find(const std::string &element, const std::string &attr, std::string &out) const {
+        bool found = false;
+        size_t pos = 0;
+        const std::string open = "<" + element;
+        while ((pos = text_.find(open, pos)) != std::string::npos) {
+            const size_t after = pos + open.size();
+            pos = after;
+            if (after >= text_.size() || !(std::isspace((unsigned char)text_[after]) || text_[after] == '/' || text_[after] == '>'))
+                continue;
+            const size_t end = text_.find('>', after);
+            const std::string body = text_.substr(after, end == std::string::npos ? std::string::npos : end - after);
+            size_t a = 0;
+            while ((a = body.find(attr, a)) != std::string::npos) {
+                const bool starts = a == 0 || std::isspace((unsigned char)body[a - 1]);
+                size_t q = a + attr.size();
+                while (q < body.size() && std::isspace((unsigned char)body[q])) ++q;
+                if (starts && q < body.size() && body[q] == '=') {
+                    ++q;
+                    while (q < body.size() && std::isspace((unsigned char)body[q])) ++q;
+                    if (q < body.size() && (body[q] == '"' || body[q] == '\'')) {
+                        const char quote = body[q];
+                        const size_t e = body.find(quote, q + 1);
+                        if (e != std::string::npos) {
+                            out = body.substr(q + 1, e - q - 1);
+                            found = true;
+                        }
+                    }
+                    break;
+                }
+                a += attr.size();
+            }
+        }
+        return found;
+    }
+    double getDouble(const std::string &element, const std::string &attr, double dflt) const {
+        std::string v;
+        return find(element, attr, v) ? std::strtod(v.c_str(), nullptr) : dflt;
+    }
+    int getInt(const std::string &element, const std::string &attr, int dflt) const {
+        std::string v;
+        return find(element, attr, v) ? (int)std::strtol(v.c_str(), nullptr, 10) : dflt;
+    }
+
+private:
+    std::string text_;
+};
+
+class KalmanFilter : public SingleTagFilter { /* KalmanFilter.h:29-133 */
+public:
+    KalmanFilter(double accelerationNoise, double initialAngle, double jolt, std::string filenamePos,
+                 std::string filenamePX4Flow, std::string filenameTag, std::string filenameImu, std::string filenameMag)
+        : SingleTagFilter(KFPOS_MODEL_PLANAR, accelerationNoise, jolt, false, 0.0, false, nullptr),
+          names_{filenamePos, filenamePX4Flow, filenameTag, filenameImu, filenameMag} {
+        std::memset(&cfg_, 0, sizeof(cfg_));
+        cfg_.init_angle = initialAngle;
+    }
+    KalmanFilter(double accelerationNoise, double initialAngle, double jolt, std::string filenamePos,
+                 std::string filenamePX4Flow, std::string filenameTag, std::string filenameImu, std::string filenameMag,
+                 Vector3 initialPosition)
+        : SingleTagFilter(KFPOS_MODEL_PLANAR, accelerationNoise, jolt, false, 0.0, true, &initialPosition),
+          names_{filenamePos, filenamePX4Flow, filenameTag, filenameImu, filenameMag} {
+        std::memset(&cfg_, 0, sizeof(cfg_));
+        cfg_.init_angle = initialAngle;
+    }
+    /* where init() finds the five XML documents; default: none, init() then returns false as the reference does
+     * when a parameter is missing (property_tree throws on the empty document, KalmanFilter.cpp:890-892) */
+    void setParamSource(ParamSource src) { source_ = std::move(src); }
+    const kfpos_planar_config &configuration() const { return cfg_; }
+
+    /* loadConfigurationFiles, KalmanFilter.cpp:748-897 */
+    bool init() override {
+        if (!h_ || !source_) return false;
+        XmlAttributes px4, uwb, imu, mag, pos;
+        std::string content;
+        if (!source_(names_[1], content) || !px4.parse(content)) return false;
+        if (!source_(names_[2], content) || !uwb.parse(content)) return false;
+        if (!source_(names_[3], content) || !imu.parse(content)) return false;
+        if (!source_(names_[4], content) || !mag.parse(content)) return false;
+        if (!source_(names_[0], content) || !pos.parse(content)) return false; /* read, nothing used (:849-887) */
+        cfg_.px4_height = px4.getDouble("px4flow", "sensorHeight", 0);
+        cfg_.px4_arm_p1 = px4.getDouble("px4flow", "armP0", 0);
+        cfg_.px4_arm_p2 = px4.getDouble("px4flow", "armP1", 0);
+        cfg_.px4_cov_velocity = px4.getDouble("px4flow", "covarianceVelocity", 0);
+        cfg_.px4_cov_gyro_z = px4.getDouble("px4flow", "covarianceGyroZ", 0);
+        cfg_.use_fixed_height = uwb.getInt("uwb", "useFixedHeight", 0) == 1;
+        cfg_.fixed_height = uwb.getDouble("uwb", "fixedHeight", 0);
+        cfg_.imu_use_fixed_cov_acc = imu.getInt("imu", "useFixedCovarianceAcceleration", 0) == 1;
+        cfg_.imu_cov_acc = imu.getDouble("imu", "covarianceAcceleration", 0);
+        cfg_.imu_use_fixed_cov_ang_vel_z = imu.getInt("imu", "useFixedCovarianceAngularVelocityZ", 0) == 1;
+        cfg_.imu_cov_ang_vel_z = imu.getDouble("imu", "covarianceAngularVelocityZ", 0);
+        cfg_.mag_angle_offset = mag.getDouble("mag", "angleOffset", 0);
+        cfg_.mag_cov = mag.getDouble("mag", "covarianceMag", 0);
+        return kfpos_set_planar(h_, &cfg_) == KFPOS_OK && kfpos_init(h_) == KFPOS_OK;
+    }
+
+    /* KalmanFilter.cpp:102-135. quality 0: the sample is dropped before the clock is read */
+    void newPX4FlowMeasurement(double integrationX, double integrationY, double integrationRotationZ,
+                               double integrationTime, int quality) override {
+        if (quality == 0) return;
+        const double f[5] = {integrationX, integrationY, integrationRotationZ, integrationTime, (double)quality};
+        const double dt = lag();
+        check(kfpos_step_sensor(h_, KFPOS_SENSOR_PX4FLOW, f, &dt, 1, &status_));
+    }
+    /* KalmanFilter.cpp:139-182 */
+    void newIMUMeasurement(VectorDim3 angularVelocity, double covarianceAngularVelocity[9], VectorDim3 linearAcceleration,
+                           double covarianceAcceleration[9]) override {
+        double d[24] = {angularVelocity.x, angularVelocity.y, angularVelocity.z};
+        std::memcpy(d + 3, covarianceAngularVelocity, 9 * sizeof(double));
+        d[12] = linearAcceleration.x; d[13] = linearAcceleration.y; d[14] = linearAcceleration.z;
+        std::memcpy(d + 15, covarianceAcceleration, 9 * sizeof(double));
+        const double dt = lag();
+        check(kfpos_step_sensor(h_, KFPOS_SENSOR_IMU, d, &dt, 1, &status_));
+    }
+    /* KalmanFilter.cpp:185-199: covarianceMag is ignored, the configured one is used */
+    void newMAGMeasurement(VectorDim3 mag, double /*covarianceMag*/[9]) override {
+        const double d[3] = {mag.x, mag.y, mag.z};
+        const double dt = lag();
+        check(kfpos_step_sensor(h_, KFPOS_SENSOR_MAG, d, &dt, 1, &status_));
+    }
+    /* KalmanFilter.cpp:201-229 */
+    void newCompassMeasurement(double compass) override {
+        const double dt = lag();
+        check(kfpos_step_sensor(h_, KFPOS_SENSOR_COMPASS, &compass, &dt, 1, &status_));
+    }
+
+protected:
+    void fillPose(Vector3 &pose, const double *x, const double *P) override {
+        pose = Vector3(); /* stateToPose, KalmanFilter.cpp:324-363 */
+        double z = 0.0;
+        check(kfpos_get_height(h_, &z));
+        pose.x = x[0]; pose.y = x[1]; pose.z = z;
+        const double half = x[6] * 0.5;
+        pose.rotZ = std::sin(half);
+        pose.rotW = std::cos(half);
+        pose.linearSpeedX = x[2]; pose.linearSpeedY = x[3];
+        pose.angularSpeedZ = x[7];
+        pose.covarianceDim = 6;
+        for (int i = 0; i < 6; ++i) pose.covarianceMatrix[i * 6 + i] = 0.01;
+        pose.covarianceMatrix[0 * 6 + 0] = P[0 * 8 + 0];
+        pose.covarianceMatrix[0 * 6 + 1] = P[0 * 8 + 1];
+        pose.covarianceMatrix[1 * 6 + 0] = P[1 * 8 + 0];
+        pose.covarianceMatrix[1 * 6 + 1] = P[1 * 8 + 1];
+        pose.covarianceMatrix[0 * 6 + 5] = P[0 * 8 + 6];
+        pose.covarianceMatrix[1 * 6 + 5] = P[1 * 8 + 6];
+        pose.covarianceMatrix[5 * 6 + 0] = P[6 * 8 + 0];
+        pose.covarianceMatrix[5 * 6 + 1] = P[6 * 8 + 1];
+        pose.covarianceMatrix[5 * 6 + 5] = P[6 * 8 + 6];
+    }
+
+private:
+    std::string names_[5];
+    ParamSource source_;
+    kfpos_planar_config cfg_;
 };
 
 } // namespace kfpos_host

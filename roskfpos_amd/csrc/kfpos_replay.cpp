@@ -10,6 +10,10 @@
  *   A <anchorId> <x> <y> <z>                          anchors topic (Posgenerator.cpp:15-39)
  *   R <t> <anchorId> <tagId> <range_mm> <seq> <err>   gtec_msgs::Ranging (one per tag-anchor range)
  *   I <t> <ax> <ay> <az> <c0> ... <c8>                sensor_msgs::Imu linear acceleration + covariance
+ *   J <t> <wx> <wy> <wz> <cw0..8> <ax> <ay> <az> <ca0..8>   the whole sensor_msgs::Imu (ALGORITHM_KF reads the yaw rate too)
+ *   X <t> <int_x> <int_y> <int_zgyro> <int_time_us> <quality>   mavros_msgs::OpticalFlowRad (Posgenerator.cpp:99-103)
+ *   C <t> <heading>                                   std_msgs::Float64 compass, what node_pos.cpp subscribes as "MAG" (:169-173)
+ *   G <t> <mx> <my> <mz>                              sensor_msgs::MagneticField -> PosGenerator::newMAGMeasurement (:106-118)
  *   P <t>                                             fixed-rate publish tick -> getPose (Posgenerator.cpp:541-548)
  *   F <t>                                             flush the open epoch (the 50 ms timer, Posgenerator.cpp:143-152)
  *
@@ -38,6 +42,11 @@ struct NodeParams { /* names and defaults: node_pos.cpp:48-109, kfpos_toa.launch
     double initPositionX = 0, initPositionY = 0, initPositionZ = 0;
     int useHeuristicIgnoreWorst = 0;
     double heuristicIgnoreThreshold = 0.5;
+    /* ALGORITHM_KF (node_pos.cpp:64-97): initAngle is only read with useStartPosition = 1; the use* switches decide
+     * which topics are subscribed; config*: files behind the five XML parameters (<param textfile=.../>) */
+    double initAngle = 0;
+    int usePX4Flow = 0, useTOA = 1, useIMU = 0, useMAG = 0;
+    std::string configPos, configPX4Flow, configUWB, configIMU, configMAG;
     std::string targetDeviceId = "", nodeName = "/kfpos"; /* topic names, node_pos.cpp:119-135 */
     int dumpMessages = 0; /* not a reference parameter: print every published message field on P ticks */
     std::string tagIds = ""; /* not a reference parameter: comma-separated hex tag ids -> batched multi-tag mode */
@@ -54,6 +63,16 @@ static bool set_param(NodeParams &p, const std::string &k, const std::string &v)
     else if (k == "initPositionZ") p.initPositionZ = atof(v.c_str());
     else if (k == "useHeuristicIgnoreWorst") p.useHeuristicIgnoreWorst = atoi(v.c_str());
     else if (k == "heuristicIgnoreThreshold") p.heuristicIgnoreThreshold = atof(v.c_str());
+    else if (k == "initAngle") p.initAngle = atof(v.c_str());
+    else if (k == "usePX4Flow") p.usePX4Flow = atoi(v.c_str());
+    else if (k == "useTOA") p.useTOA = atoi(v.c_str());
+    else if (k == "useIMU") p.useIMU = atoi(v.c_str());
+    else if (k == "useMAG") p.useMAG = atoi(v.c_str());
+    else if (k == "configPos") p.configPos = v;
+    else if (k == "configPX4Flow") p.configPX4Flow = v;
+    else if (k == "configUWB") p.configUWB = v;
+    else if (k == "configIMU") p.configIMU = v;
+    else if (k == "configMAG") p.configMAG = v;
     else if (k == "tagIds") p.tagIds = v;
     else if (k == "targetDeviceId") p.targetDeviceId = v;
     else if (k == "nodeName") p.nodeName = v;
@@ -79,8 +98,20 @@ static std::unique_ptr<SingleTagFilter> make_algorithm(const NodeParams &p) {
         if (!p.useStartPosition) return std::unique_ptr<SingleTagFilter>(new KalmanFilterTOAIMU(p.accelNoise, p.jolt));
         return std::unique_ptr<SingleTagFilter>(new KalmanFilterTOAIMU(p.accelNoise, p.jolt, init));
     }
-    throw std::invalid_argument("algorithm must be ALGORITHM_KF_TOA or ALGORITHM_KF_TOA_IMU "
-                                "(ALGORITHM_KF / ALGORITHM_ML are outside this core: DESIGN.md)");
+    if (p.algorithm == "ALGORITHM_KF") { /* Posgenerator.cpp:517-522 */
+        const double angle = p.useStartPosition == 1 ? p.initAngle : 0.0; /* node_pos.cpp:68-73 */
+        std::unique_ptr<KalmanFilter> kf(
+            !p.useStartPosition ? new KalmanFilter(p.accelNoise, angle, p.jolt, "configPos", "configPX4Flow", "configUWB",
+                                                   "configIMU", "configMAG")
+                                : new KalmanFilter(p.accelNoise, angle, p.jolt, "configPos", "configPX4Flow", "configUWB",
+                                                   "configIMU", "configMAG", init));
+        kf->setParamSource(fileParamSource({{"configPos", p.configPos}, {"configPX4Flow", p.configPX4Flow},
+                                            {"configUWB", p.configUWB}, {"configIMU", p.configIMU},
+                                            {"configMAG", p.configMAG}}));
+        return std::unique_ptr<SingleTagFilter>(kf.release());
+    }
+    throw std::invalid_argument("algorithm must be ALGORITHM_KF_TOA, ALGORITHM_KF_TOA_IMU or ALGORITHM_KF "
+                                "(single-tag ALGORITHM_ML: use the C ABI, KFPOS_MODEL_ML)");
 }
 
 /* The ranging epoch table of PosGenerator for one tag: ranges keyed by anchor column, flushed when a
@@ -234,7 +265,11 @@ int main(int argc, char **argv) {
         std::unique_ptr<SingleTagFilter> alg = make_algorithm(p);
         double now = 0.0;
         alg->setClock([&now] { return now; });
-        alg->init();
+        if (!alg->init()) throw std::runtime_error("init() failed: a config* XML parameter is missing or malformed");
+        /* which topics node_pos.cpp subscribes (:146-173) */
+        const bool kf = p.algorithm == "ALGORITHM_KF";
+        const bool subTOA = kf ? p.useTOA == 1 : true, subIMU = kf ? p.useIMU == 1 : p.algorithm == "ALGORITHM_KF_TOA_IMU";
+        const bool subPX4 = kf && p.usePX4Flow == 1, subMAG = kf && p.useMAG == 1;
         EpochAssembler ep;
         PosePublisher publisher;
         std::ifstream in(trace);
@@ -251,19 +286,42 @@ int main(int argc, char **argv) {
             } else if (kind == 'R') {
                 int anchorId, tag, seq; double t, mm, e;
                 ss >> t >> anchorId >> tag >> mm >> seq >> e;
-                if (tag != tagId) continue; /* Posgenerator.cpp:203 */
+                if (tag != tagId || !subTOA) continue; /* Posgenerator.cpp:203 */
                 now = t;
                 ep.ranging(*alg, anchorId, mm, seq, e);
             } else if (kind == 'F') {
                 ss >> now;
                 ep.flush(*alg);
-            } else if (kind == 'I') {
+            } else if (kind == 'I' && subIMU) {
                 double t, c[9]; VectorDim3 a, w = {0, 0, 0};
                 ss >> t >> a.x >> a.y >> a.z;
                 for (double &v : c) ss >> v;
                 now = t;
                 double cw[9] = {0};
                 alg->newIMUMeasurement(w, cw, a, c);
+            } else if (kind == 'J' && subIMU) {
+                double t, cw[9], ca[9]; VectorDim3 a, w;
+                ss >> t >> w.x >> w.y >> w.z;
+                for (double &v : cw) ss >> v;
+                ss >> a.x >> a.y >> a.z;
+                for (double &v : ca) ss >> v;
+                now = t;
+                alg->newIMUMeasurement(w, cw, a, ca);
+            } else if (kind == 'X' && subPX4) {
+                double t, ix, iy, iz, us; int q;
+                ss >> t >> ix >> iy >> iz >> us >> q;
+                now = t;
+                if (us > 0 && q > 0) alg->newPX4FlowMeasurement(ix, iy, iz, us, q); /* Posgenerator.cpp:100 */
+            } else if (kind == 'C' && subMAG) {
+                double t, heading;
+                ss >> t >> heading;
+                now = t;
+                alg->newCompassMeasurement(heading);
+            } else if (kind == 'G' && subMAG) {
+                double t, c[9] = {0}; VectorDim3 m;
+                ss >> t >> m.x >> m.y >> m.z;
+                now = t;
+                alg->newMAGMeasurement(m, c);
             } else if (kind == 'P' && p.dumpMessages) {
                 ss >> now;
                 const bool ok = publisher.fixedRateReport(*alg, now);

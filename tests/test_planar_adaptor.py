@@ -1,0 +1,150 @@
+"""Host mirror of the reference's KalmanFilter class (kfpos_adaptor.h) and ALGORITHM_KF in the replay tool."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from planar import CFG, PlanarOracle
+from roskfpos_amd.synth import Workload
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPLAY = os.path.join(ROOT, "roskfpos_amd", "csrc", "kfpos_replay")
+
+XML = {
+    "configUWB": '<config>\n <!-- <uwb useFixedHeight="0" fixedHeight="9.9" tagId="6e5b"/> -->\n'
+                 ' <uwb useFixedHeight="1" fixedHeight="1.0" tagId="0"/>\n</config>\n',
+    "configPX4Flow": '<config>\n  <px4flow armP0="0.05" armP1="-0.02" useFixedSensorHeight="1" sensorHeight="0.8" '
+                     'sensorInitAngle ="-1.57" covarianceVelocity="0.002" covarianceGyroZ="0.001"/>\n</config>',
+    "configIMU": '<config>\n <imu useFixedCovarianceAcceleration="0" covarianceAcceleration="0.02"  '
+                 'useFixedCovarianceAngularVelocityZ="1" covarianceAngularVelocityZ="0.0005"/> \n</config>',
+    "configMAG": '<config>\n<mag angleOffset="0.1" covarianceMag="0.01"/>\n</config>',
+    "configPos": '<config>\n <algorithm type="1" variant="0"/>\n</config>',
+}
+
+
+def test_xml_attribute_reader(tmp_path):
+    """The slice of boost::property_tree the reference relies on: comments skipped, defaults, last element wins."""
+    src = tmp_path / "x.cpp"
+    src.write_text(r'''
+#include "kfpos_adaptor.h"
+#include <cstdio>
+using namespace kfpos_host;
+int main() {
+    XmlAttributes a;
+    if (!a.parse("<config>\n<!-- <uwb useFixedHeight=\"0\" fixedHeight=\"9.9\"/> -->\n"
+                 "<uwb useFixedHeight=\"1\" fixedHeight=\"1.049\" tagId=\"0\"/>\n"
+                 "<uwbx fixedHeight=\"7\"/><px4flow sensorInitAngle =\"-1.5\" armP0='2'/></config>")) return 1;
+    if (a.getInt("uwb", "useFixedHeight", 0) != 1) return 2;
+    if (a.getDouble("uwb", "fixedHeight", 0) != 1.049) return 3;
+    if (a.getDouble("uwb", "missing", 4.5) != 4.5) return 4;
+    if (a.getDouble("px4flow", "sensorInitAngle", 0) != -1.5) return 5;
+    if (a.getDouble("px4flow", "armP0", 0) != 2.0) return 6;
+    if (a.getDouble("mag", "angleOffset", -3) != -3) return 7;
+    if (a.getDouble("uwb", "Height", -1) != -1) return 8;   /* no suffix match on "fixedHeight" */
+    XmlAttributes b;
+    if (b.parse("<notconfig/>")) return 9;
+    XmlAttributes c;
+    if (!c.parse("<config><mag angleOffset=\"1\"/><mag angleOffset=\"2\"/></config>")) return 10;
+    if (c.getDouble("mag", "angleOffset", 0) != 2.0) return 11;
+    std::puts("ok");
+    return 0;
+}
+''')
+    exe = tmp_path / "x"
+    subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-I",
+                           os.path.join(ROOT, "roskfpos_amd", "csrc"), "-fsyntax-only", str(src)])
+    # link against the HIP library only to resolve the inline classes' symbols; nothing on the GPU is called
+    subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-I",
+                           os.path.join(ROOT, "roskfpos_amd", "csrc"), "-o", str(exe), str(src), "-L",
+                           os.path.join(ROOT, "roskfpos_amd", "csrc"), "-lkfpos_hip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "roskfpos_amd", "csrc")])
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", (r.returncode, r.stderr)
+
+
+def _write_trace(path, w, S, tag):
+    lines = [f"A {100 + a} {x:.17g} {y:.17g} {z:.17g}" for a, (x, y, z) in enumerate(w.anchors)]
+    t, calls = 10.0, []
+    cw = np.eye(3).ravel() * 1e-4
+    ca = w.accel_cov()[tag]
+    f17 = lambda v: " ".join("%.17g" % x for x in v)
+    for s in range(S):
+        t += w.dt_of(s) if s else 0.0
+        if s >= 2:
+            wv, la = w.planar_imu(s)
+            lines.append(f"J {t - 0.03:.9f} {f17(wv[tag])} {f17(cw)} {f17(la[tag])} {f17(ca)}")
+            calls.append(("imu", t - 0.03, s))
+        if s >= 3:
+            f = w.px4flow(s)[tag]
+            lines.append(f"X {t - 0.02:.9f} {f17(f[:4])} {int(f[4])}")
+            if f[4] > 0:
+                calls.append(("px4", t - 0.02, s))
+        if s >= 4:
+            lines.append(f"C {t - 0.01:.9f} {w.compass(s)[tag]:.17g}")
+            calls.append(("compass", t - 0.01, s))
+        for a_idx, mm in enumerate(w.ranges_mm(s)[tag]):
+            lines.append(f"R {t:.9f} {100 + a_idx} 0 {int(mm)}.3 {s % 256} 0.0025")
+        lines.append(f"F {t:.9f}")
+        calls.append(("toa", t, s))
+        lines.append(f"P {t + 0.02:.9f}")
+        calls.append(("pose", t + 0.02, s))
+    open(path, "w").write("\n".join(lines) + "\n")
+    return calls
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fixed", [1, 0])
+def test_replay_algorithm_kf_matches_oracle(tmp_path, fixed):
+    S, tag = 40, 2
+    w = Workload(8, 8)
+    trace = str(tmp_path / "trace.txt")
+    calls = _write_trace(trace, w, S, tag)
+    files = {}
+    for k, v in XML.items():
+        files[k] = str(tmp_path / (k + ".xml"))
+        open(files[k], "w").write(v)
+    p0 = w.init_positions()[tag]
+    out = subprocess.run([REPLAY, "algorithm:=ALGORITHM_KF", f"useStartPosition:={fixed}", "initAngle:=0.3",
+                          f"initPositionX:={p0[0]:.17g}", f"initPositionY:={p0[1]:.17g}", "initPositionZ:=5.5",
+                          "accelNoise:=0.5", "jolt:=0.5", "usePX4Flow:=1", "useIMU:=1", "useMAG:=1"] +
+                         [f"{k}:={v}" for k, v in files.items()] + [trace],
+                         capture_output=True, text=True, check=True).stdout
+    got = np.array([[float(v) for v in ln.split()[2:]] for ln in out.splitlines() if ln.startswith("P")])
+    assert got.shape == (S, 7) and np.all(got[:, 0] == 1)
+
+    # the same call sequence through the oracle; initAngle is only read with useStartPosition = 1
+    cfg = dict(CFG, init_angle=0.3 if fixed else 0.0)
+    w1 = Workload(1, 8, tag0=tag)
+    orc = PlanarOracle(w1, cfg, p0[None] if fixed else None)
+    cw, ca = np.eye(3).reshape(1, 9) * 1e-4, w1.accel_cov()
+    last, want = None, []
+    for kind, t, s in calls:
+        if kind == "pose":
+            pos, cov, _, _ = orc.get_pose(t - last)
+            want.append([pos[0, 0], pos[0, 1], pos[0, 2], cov[0, 0, 0], cov[0, 1, 1], cov[0, 2, 2]])
+            continue
+        dt = 0.1 if last is None else t - last
+        last = t
+        if kind == "imu":
+            wv, la = w1.planar_imu(s)
+            orc.step_planar_imu(wv, cw, la, ca, dt)
+        elif kind == "px4":
+            orc.step_px4flow(w1.px4flow(s), dt)
+        elif kind == "compass":
+            orc.step_compass(w1.compass(s), dt)
+        else:
+            orc.step_toa(w1.ranges_mm(s), w1.err_est(), dt)
+    want = np.array(want)
+    ok = np.isfinite(want[:, 0])
+    assert ok.sum() >= S - 2
+    np.testing.assert_allclose(got[ok, 1:4], want[ok, :3], rtol=0, atol=1e-8)
+    np.testing.assert_allclose(got[ok, 4:7], want[ok, 3:6], rtol=1e-6, atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_replay_algorithm_kf_init_fails_without_configuration(tmp_path):
+    trace = str(tmp_path / "t.txt")
+    open(trace, "w").write("A 1 0 0 0\n")
+    r = subprocess.run([REPLAY, "algorithm:=ALGORITHM_KF", trace], capture_output=True, text=True)
+    assert r.returncode == 1 and "init() failed" in r.stderr

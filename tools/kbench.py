@@ -28,7 +28,16 @@ CONFIGS = {
     "c3_f32": (1, 65536, 8, capi.STORE_F32, 0, False, 544),
     "c5": (0, 262144, 16, capi.STORE_F32, 2, False, 344),
     "iw8": (0, 65536, 8, capi.STORE_F64, 0, True, 560),
+    # 8-state planar filter (KalmanFilter): ranging-only bank, and the same with IMU + compass samples latched
+    # (every ranging epoch then carries 4 sensor rows; LDS-staged kernel). state 7+36 doubles r/w, epoch 96 B,
+    # trajectory 24 B, flags + status 12 B
+    "planar": (3, 65536, 8, capi.STORE_F64, 0, False, 820),
+    "planar_sens": (3, 65536, 8, capi.STORE_F64, 0, False, 820 + 80),
 }
+PLANAR_CFG = dict(use_fixed_height=1, fixed_height=1.0, init_angle=0.3, px4_height=0.8, px4_arm_p1=0.05,
+                  px4_arm_p2=-0.02, px4_cov_velocity=0.002, px4_cov_gyro_z=0.001, imu_use_fixed_cov_acc=0,
+                  imu_cov_acc=0.02, imu_use_fixed_cov_ang_vel_z=1, imu_cov_ang_vel_z=0.0005, mag_angle_offset=0.0,
+                  mag_cov=0.01)
 
 
 def run(name, steps, warmup):
@@ -47,7 +56,11 @@ def run(name, steps, warmup):
     cov = torch.from_numpy(np.ascontiguousarray(w.accel_cov(real).T)).to(dev)
     dts = np.array([w.dt_of(s) for s in range(S)])
     bank = capi.KfposBank(model, T, w.anchors, storage=storage, top_n=top_n, ignore_worst=iw,
-                          init_pos=w.init_positions())
+                          init_pos=w.init_positions(), planar=PLANAR_CFG if model == 3 else None)
+    if name == "planar_sens":  # latch an IMU and a compass sample: ranging epochs carry their rows from now on
+        wv, la = w.planar_imu(0)
+        bank.step_planar_imu(wv, np.tile(np.eye(3).ravel() * 1e-4, (T, 1)), la, w.accel_cov(), 0.1)
+        bank.step_compass(w.compass(0), 0.0)
     stream = torch.cuda.current_stream().cuda_stream
     status = torch.zeros(T, dtype=torch.int32, device=dev)
 
@@ -64,6 +77,8 @@ def run(name, steps, warmup):
     st = status.cpu().numpy().astype(np.uint32)
     x, _, _ = bank.get_state()
     truth = w.position(w.time_of(S - 1))
+    if model == 3:
+        x, truth = x[:, :2], truth[:, :2]
     out = {"config": name, "tags": T, "anchors": A, "us_per_launch": round(us, 2),
            "tag_steps_per_s": T / us * 1e6, "algo_GBps": nbytes * T / us / 1e3,
            "hbm_frac": nbytes * T / us / 1e3 / 8000.0,
