@@ -42,8 +42,10 @@
 #define KFPOS_FN KFPOS_HD inline __attribute__((always_inline))
 #if defined(__clang__)
 #define KFPOS_UNROLL _Pragma("unroll")
+#define KFPOS_NOUNROLL _Pragma("nounroll")
 #else
 #define KFPOS_UNROLL
+#define KFPOS_NOUNROLL
 #endif
 
 namespace kfpos {
@@ -225,6 +227,7 @@ KFPOS_FN void chol3_psd(const double m[6], double l[6], double il[3]) {
  * stride = wavefront width in LDS (conflict-free), 1 in the host emulation. */
 struct Scratch {
     static constexpr int NA = 0; /* anchor count only known at run time */
+    static constexpr int CHUNK = 0;
     double *r, *e, *w;
     int stride;
     KFPOS_HD double R(int a) const { return r[a * stride]; }
@@ -233,11 +236,23 @@ struct Scratch {
     KFPOS_HD void setW(int a, double v) { w[a * stride] = v; }
     KFPOS_HD double Rdyn(int a) const { return r[a * stride]; } /* a not a compile-time constant */
 };
+/* Scratch with the anchor count fixed at compile time but the epoch still outside the register file: the anchor
+ * loops unroll (coordinates become batched constant-offset scalar loads, the LDS reads of a sweep are issued
+ * back to back) without the 6 registers per anchor that RegScratch costs -- for counts too large to keep in
+ * registers next to the covariance (16 anchors: BASELINE config 5). */
+template <int N>
+struct StaticScratch : Scratch {
+    static constexpr int NA = N;
+    /* anchors per unrolled group: unrolling all 16 at once lets the scheduler interleave 16 rsqrt chains and spills
+     * (156-452 bytes/lane measured); groups of 8 keep the live set of the 8-anchor kernels */
+    static constexpr int CHUNK = N > 8 ? 8 : 0;
+};
 /* Same view with the anchor count fixed at compile time: the epoch stays in registers, every anchor
  * loop unrolls, anchor coordinates become constant-offset scalar loads that the compiler batches. */
 template <int N>
 struct RegScratch {
     static constexpr int NA = N;
+    static constexpr int CHUNK = 0; /* register arrays need compile-time indices: one fully unrolled group */
     double r[N], e[N], w[N];
     KFPOS_HD double R(int a) const { return r[a]; }
     KFPOS_HD double E(int a) const { return e[a]; }
@@ -253,7 +268,14 @@ struct RegScratch {
 /* f(a) for every anchor column; fully unrolled when the count is static */
 template <class SC, class F>
 KFPOS_FN void for_anchors(const Params &pr, F &&f) {
-    if constexpr (SC::NA > 0) {
+    if constexpr (SC::NA > 0 && SC::CHUNK > 0) {
+        static_assert(SC::NA % SC::CHUNK == 0, "anchor count must be a multiple of the unroll group");
+        KFPOS_NOUNROLL
+        for (int c = 0; c < SC::NA; c += SC::CHUNK) {
+            KFPOS_UNROLL
+            for (int k = 0; k < SC::CHUNK; ++k) f(c + k);
+        }
+    } else if constexpr (SC::NA > 0) {
         KFPOS_UNROLL
         for (int a = 0; a < SC::NA; ++a) f(a);
     } else {

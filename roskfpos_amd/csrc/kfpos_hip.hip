@@ -162,6 +162,23 @@ __device__ inline Scratch stage_epoch_lds(const KArgs &a, double *lds, int lane,
     }
     return sc;
 }
+/* anchor count known at compile time: all 2 N loads first, then the conversions and the LDS stores */
+template <typename MREAL, int N>
+__device__ inline StaticScratch<N> stage_epoch_lds_n(const KArgs &a, double *lds, int lane, size_t t, int s) {
+    StaticScratch<N> sc;
+    sc.r = lds + lane;
+    sc.e = lds + (size_t)N * WAVE + lane;
+    sc.w = lds + 2 * (size_t)N * WAVE + lane;
+    sc.stride = WAVE;
+    RawEpoch<MREAL, N> raw;
+    fetch_epoch<MREAL, N>(a, t, s, raw);
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        sc.r[k * WAVE] = raw.mm[k] > 0 ? kf_mm_to_m(raw.mm[k]) : 0.0;
+        sc.e[k * WAVE] = (double)raw.e[k];
+    }
+    return sc;
+}
 __device__ inline double epoch_dt(const KArgs &a, size_t t, int s) {
     return a.n_steps > 1 ? a.dt_steps[s] : (a.dt ? a.dt[t] : a.dt_shared);
 }
@@ -199,6 +216,9 @@ __global__ __launch_bounds__(WAVE) void k_step_toa6(const KArgs a) {
             RegScratch<AS> sc;
             unpack_epoch<MREAL, AS>(raw, sc);
             if (e + 1 < a.n_steps) fetch_epoch<MREAL, AS>(a, t, e + 1, raw); /* next epoch in flight */
+            s = step_toa6<SYMM>(tg, sc, pr, dt);
+        } else if constexpr (AS < 0) { /* compile-time count, epoch in LDS */
+            StaticScratch<-AS> sc = stage_epoch_lds_n<MREAL, -AS>(a, lds, lane, t, e);
             s = step_toa6<SYMM>(tg, sc, pr, dt);
         } else {
             Scratch sc = stage_epoch_lds<MREAL>(a, lds, lane, t, e);
@@ -795,11 +815,17 @@ typedef void (*step_kernel_t)(const KArgs);
  * 96 more live registers push the kernel into scratch spills (no faster than the generic kernel on config 5,
  * 165 vs 170 us) and, on partially filled wavefronts, the spilled build returned wrong, run-to-run
  * varying positions -- no kernel in this library may use scratch (checked at build time). */
-int static_anchors(const kfpos_handle *h) { return h->cfg.max_anchors == 8 ? 8 : 0; }
+int static_anchors(const kfpos_handle *h) {
+    if (h->cfg.max_anchors == 8) return 8;
+    /* 16 anchors (BASELINE config 5): compile-time loops over an LDS-resident epoch (StaticScratch), 6-state only */
+    if (h->cfg.max_anchors == 16 && h->cfg.model == KFPOS_MODEL_TOA) return -16;
+    return 0;
+}
 
 template <bool SYMM, typename REAL, typename MREAL>
 step_kernel_t toa6_kernel(int as) {
     if (as == 8) return k_step_toa6<SYMM, REAL, MREAL, 8>;
+    if (as == -16) return k_step_toa6<SYMM, REAL, MREAL, -16>;
     return k_step_toa6<SYMM, REAL, MREAL, 0>;
 }
 template <typename REAL, typename MREAL>
@@ -851,7 +877,7 @@ step_kernel_t step_kernel(const kfpos_handle *h, bool sensor_call = false) {
 
 int launch_step(kfpos_handle *h, const KArgs &a, hipStream_t s) {
     const int blocks = (h->cfg.n_tags + WAVE - 1) / WAVE;
-    const bool generic = h->force_generic || static_anchors(h) == 0 ||
+    const bool generic = h->force_generic || static_anchors(h) <= 0 ||
                          (h->cfg.model == KFPOS_MODEL_PLANAR && h->planar_sensors);
     const bool planar_sensor = h->cfg.model == KFPOS_MODEL_PLANAR && a.mode != 0;
     size_t lds = (a.mode == MODE_IMU_ONLY || planar_sensor || !generic) ? 0 : lds_bytes(h);

@@ -145,6 +145,17 @@ static uint32_t step_static(kfe_bank *b, int t, const int32_t *mm, const double 
     return step_imu9(b->t9[t], sc, b->pr, lag, true, b->imu[t]);
 }
 
+/* compile-time anchor count over the strided scratch (the LDS-resident epoch of the 16-anchor kernels) */
+template <int AS>
+static uint32_t step_static_lds(kfe_bank *b, int t, const int32_t *mm, const double *err, double lag,
+                                std::vector<double> &buf) {
+    StaticScratch<AS> sc;
+    fill_scratch(b, mm, err, buf, sc);
+    if (b->model == 0 && !b->full) return step_toa6(b->t6s[t], sc, b->pr, lag);
+    if (b->model == 0) return step_toa6(b->t6f[t], sc, b->pr, lag);
+    return step_imu9(b->t9[t], sc, b->pr, lag, true, b->imu[t]);
+}
+
 extern "C" {
 
 void kfe_step_toa(kfe_bank *b, const int32_t *range_mm, const double *err_est, const double *dt, int dt_len,
@@ -160,7 +171,8 @@ void kfe_step_toa(kfe_bank *b, const int32_t *range_mm, const double *err_est, c
             if (status) status[t] = ST_SKIPPED;
             continue;
         }
-        if (b->use_static && b->A == 8) st = step_static<8>(b, t, mm, err, lag);
+        if (b->use_static == 2 && b->A == 16 && b->model <= 1) st = step_static_lds<16>(b, t, mm, err, lag, buf);
+        else if (b->use_static && b->A == 8) st = step_static<8>(b, t, mm, err, lag);
         else if (b->use_static && b->A == 16) st = step_static<16>(b, t, mm, err, lag);
         else if (b->use_static && b->A == 4) st = step_static<4>(b, t, mm, err, lag);
         else {

@@ -150,6 +150,10 @@ class EmuStaticImpl(EmuImpl):
     static = True
 
 
+class EmuStaticLdsImpl(EmuImpl):
+    static = 2  # compile-time anchor count over the strided (LDS) scratch: the 16-anchor kernels
+
+
 class GpuImpl:
     """The product path: libkfpos_hip.so through the C ABI (host-buffer entry points)."""
 

@@ -9,14 +9,14 @@ import numpy as np
 import pytest
 
 from cases import CASES, CASE_BY_NAME, drive, rms_and_max
-from impls import EmuImpl, EmuStaticImpl, OracleImpl
+from impls import EmuImpl, EmuStaticImpl, EmuStaticLdsImpl, OracleImpl
 
 # Bar from BASELINE.json: <= 1e-6 m RMS. Everything except the one documented case sits near 1e-12.
 TOL_RMS = {"toa6_A8_mlinit": 1e-6}
 TOL_DEFAULT_RMS, TOL_DEFAULT_MAX = 1e-9, 1e-8
 
 
-@pytest.mark.parametrize("impl", [EmuImpl, EmuStaticImpl], ids=["generic", "static"])
+@pytest.mark.parametrize("impl", [EmuImpl, EmuStaticImpl, EmuStaticLdsImpl], ids=["generic", "static", "static-lds"])
 @pytest.mark.parametrize("case", CASES, ids=[c.name for c in CASES])
 def test_kernel_math_matches_oracle(case, impl):
     """generic = run-time anchor count, epoch staged per lane (LDS on the GPU); static = anchor count fixed at
