@@ -810,11 +810,11 @@ void fill_args(const kfpos_handle *h, KArgs &a) {
 
 typedef void (*step_kernel_t)(const KArgs);
 
-/* Anchor-count specialisation: 8 anchors (BASELINE configs 2-4) keep the epoch in registers; every other
- * count runs the generic LDS-staged kernel (AS = 0). A 16-anchor specialisation was measured and dropped:
- * 96 more live registers push the kernel into scratch spills (no faster than the generic kernel on config 5,
- * 165 vs 170 us) and, on partially filled wavefronts, the spilled build returned wrong, run-to-run
- * varying positions -- no kernel in this library may use scratch (checked at build time). */
+/* Anchor-count specialisation. 8 anchors (BASELINE configs 2-4): epoch in registers (RegScratch), returns 8. 16 anchors
+ * (config 5, 6-state): a register-resident epoch costs 96 more live registers and spills (measured: no faster than
+ * the run-time loop, and on partially filled wavefronts the spilled build returned wrong, run-to-run varying
+ * positions -- no kernel in this library may use scratch, checked at build time), so the epoch stays in LDS and only
+ * the anchor loops are compile-time, in groups of 8 (StaticScratch): returns -16. Everything else: 0, the run-time loop. */
 int static_anchors(const kfpos_handle *h) {
     if (h->cfg.max_anchors == 8) return 8;
     /* 16 anchors (BASELINE config 5): compile-time loops over an LDS-resident epoch (StaticScratch), 6-state only */

@@ -20,6 +20,11 @@
  * flushed epochs are handed to the GPU together: one kfpos_step_toa call per round, with the
  * estimator's wall-clock timeLag computed per tag and dt < 0 for the tags that have nothing this round.
  * The caller supplies time (seconds, monotonic) with every event, as the adaptor does.
+ *
+ * The other sensor callbacks of PosGenerator (Posgenerator.cpp:99-141) are accepted per tag too (onImu,
+ * onPX4Flow, onCompass, onMag): they queue behind that tag's pending ranging epochs, so each filter sees its
+ * calls in arrival order, and a round hands every kind to the GPU in one call (kfpos_step_imu for the 9-state
+ * filter, kfpos_step_sensor for the planar one; the 6-state filter ignores them like the reference does).
  */
 #ifndef KFPOS_INGEST_H
 #define KFPOS_INGEST_H
@@ -85,6 +90,26 @@ public:
         tg.armed = true;
     }
 
+    /* sensor_msgs::Imu -> PosGenerator::newIMUMeasurement (Posgenerator.cpp:126-141) */
+    void onImu(double now, int tagId, const double angVel[3], const double covAngVel[9], const double linAcc[3],
+               const double covAcc[9]) {
+        double d[24];
+        for (int k = 0; k < 3; ++k) { d[k] = angVel[k]; d[12 + k] = linAcc[k]; }
+        for (int k = 0; k < 9; ++k) { d[3 + k] = covAngVel[k]; d[15 + k] = covAcc[k]; }
+        enqueueSensor(now, tagId, KFPOS_SENSOR_IMU, d, 24);
+    }
+    /* mavros_msgs::OpticalFlowRad -> newPX4FlowMeasurement, gated as Posgenerator.cpp:100 does */
+    void onPX4Flow(double now, int tagId, double integratedX, double integratedY, double integratedZgyro,
+                   double integrationTimeUs, int quality) {
+        if (!(integrationTimeUs > 0 && quality > 0)) return;
+        const double d[5] = {integratedX, integratedY, integratedZgyro, integrationTimeUs, (double)quality};
+        enqueueSensor(now, tagId, KFPOS_SENSOR_PX4FLOW, d, 5);
+    }
+    /* std_msgs::Float64 -> newCompassMeasurement (:121-123) */
+    void onCompass(double now, int tagId, double heading) { enqueueSensor(now, tagId, KFPOS_SENSOR_COMPASS, &heading, 1); }
+    /* sensor_msgs::MagneticField -> newMAGMeasurement (:106-118) */
+    void onMag(double now, int tagId, const double field[3]) { enqueueSensor(now, tagId, KFPOS_SENSOR_MAG, field, 3); }
+
     /* Advance time: fire the 50 ms deadlines that have passed (timerRangingCallback), then hand every
      * pending epoch to the GPU. Returns the number of estimator calls made (tag-epochs). */
     int poll(double now) {
@@ -117,9 +142,29 @@ private:
     struct Pending {
         int row;
         double time;
+        int kind = 0; /* 0: ranging epoch, else KFPOS_SENSOR_* */
         std::vector<int32_t> mm;
-        std::vector<double> err;
+        std::vector<double> err; /* ranging: errorEstimation row; sensor: the sample */
     };
+
+    void enqueueSensor(double now, int tagId, int kind, const double *data, int n) {
+        auto it = row_.find(tagId);
+        if (it == row_.end()) return;
+        /* the empty virtuals of PositionEstimationAlgorithm.h:26-35 do not touch the filter, nor its clock */
+        const int dim = kfpos_state_dim(h_);
+        if (!(dim == 8 || (dim == 9 && kind == KFPOS_SENSOR_IMU))) return;
+        Tag &tg = tags_[it->second];
+        if (tg.armed && tg.deadline <= now) { /* the ranging timer fired first */
+            tg.armed = false;
+            enqueueFlush(it->second, tg.deadline);
+        }
+        Pending p;
+        p.row = it->second;
+        p.time = now;
+        p.kind = kind;
+        p.err.assign(data, data + n);
+        queue_.push_back(std::move(p));
+    }
 
     /* sendRangingMeasurementIfAvailable (:155-198): a snapshot of the current sequence row */
     void enqueueFlush(int row, double now) {
@@ -134,37 +179,81 @@ private:
         queue_.push_back(std::move(p));
     }
 
-    /* One kfpos_step_toa per round; a round takes at most one pending epoch per tag, in arrival order. */
+    static int sensorWidth(int kind) {
+        return kind == KFPOS_SENSOR_PX4FLOW ? 5 : kind == KFPOS_SENSOR_IMU ? 24 : kind == KFPOS_SENSOR_MAG ? 3 : 1;
+    }
+    static void check(int rc, const char *what) {
+        if (rc != KFPOS_OK)
+            throw std::runtime_error(std::string(what) + ": " + kfpos_strerror(rc) + " " + kfpos_last_error());
+    }
+
+    /* A round takes at most one pending call per tag, in arrival order, and makes one batched call per kind
+     * present (tags without a call of that kind get dt < 0). Tags are independent, so the order of the kinds
+     * inside a round does not matter. */
     int drain() {
         int calls = 0;
+        const int state_dim = kfpos_state_dim(h_);
         while (!queue_.empty()) {
-            std::vector<int32_t> mm((size_t)T_ * A_, 0);
-            std::vector<double> err64((size_t)T_ * A_, 1.0), dt(T_, -1.0);
             std::vector<char> taken(T_, 0);
-            std::vector<Pending> rest;
+            std::vector<Pending> round, rest;
             for (Pending &p : queue_) {
                 if (taken[p.row]) { rest.push_back(std::move(p)); continue; }
                 taken[p.row] = 1;
-                Tag &tg = tags_[p.row];
-                dt[p.row] = tg.started ? p.time - tg.last : 0.1; /* KalmanFilterTOA.cpp:78-88 */
-                tg.last = p.time;
-                tg.started = true;
-                for (int a = 0; a < A_; ++a) {
-                    mm[(size_t)p.row * A_ + a] = p.mm[a] > 0 ? p.mm[a] : 0; /* only entries > 0 (:483) */
-                    err64[(size_t)p.row * A_ + a] = p.err[a];
-                }
-                ++calls;
+                round.push_back(std::move(p));
             }
             queue_.swap(rest);
-            int rc;
-            if (real_ == 4) {
-                std::vector<float> e32(err64.begin(), err64.end());
-                rc = kfpos_step_toa(h_, mm.data(), e32.data(), dt.data(), T_, nullptr);
-            } else {
-                rc = kfpos_step_toa(h_, mm.data(), err64.data(), dt.data(), T_, nullptr);
+            std::vector<double> lag(round.size());
+            for (size_t i = 0; i < round.size(); ++i) { /* every call reads the filter's clock, KalmanFilterTOA.cpp:78-88 */
+                Tag &tg = tags_[round[i].row];
+                lag[i] = tg.started ? round[i].time - tg.last : 0.1;
+                tg.last = round[i].time;
+                tg.started = true;
             }
-            if (rc != KFPOS_OK)
-                throw std::runtime_error(std::string("kfpos_step_toa: ") + kfpos_strerror(rc) + " " + kfpos_last_error());
+            for (int kind = 0; kind <= KFPOS_SENSOR_COMPASS; ++kind) {
+                std::vector<double> dt(T_, -1.0);
+                int n = 0;
+                for (size_t i = 0; i < round.size(); ++i)
+                    if (round[i].kind == kind) { dt[round[i].row] = lag[i]; ++n; }
+                if (n == 0) continue;
+                calls += n;
+                if (kind == 0) {
+                    std::vector<int32_t> mm((size_t)T_ * A_, 0);
+                    std::vector<double> err64((size_t)T_ * A_, 1.0);
+                    for (const Pending &p : round) {
+                        if (p.kind != 0) continue;
+                        for (int a = 0; a < A_; ++a) {
+                            mm[(size_t)p.row * A_ + a] = p.mm[a] > 0 ? p.mm[a] : 0; /* only entries > 0 (:483) */
+                            err64[(size_t)p.row * A_ + a] = p.err[a];
+                        }
+                    }
+                    if (real_ == 4) {
+                        std::vector<float> e32(err64.begin(), err64.end());
+                        check(kfpos_step_toa(h_, mm.data(), e32.data(), dt.data(), T_, nullptr), "kfpos_step_toa");
+                    } else {
+                        check(kfpos_step_toa(h_, mm.data(), err64.data(), dt.data(), T_, nullptr), "kfpos_step_toa");
+                    }
+                } else if (state_dim == 8) { /* planar filter: the sample as the reference callback passes it */
+                    const int C = sensorWidth(kind);
+                    std::vector<double> data((size_t)T_ * C, 0.0);
+                    for (const Pending &p : round)
+                        if (p.kind == kind) std::copy(p.err.begin(), p.err.end(), data.begin() + (size_t)p.row * C);
+                    check(kfpos_step_sensor(h_, kind, data.data(), dt.data(), T_, nullptr), "kfpos_step_sensor");
+                } else if (state_dim == 9 && kind == KFPOS_SENSOR_IMU) { /* KalmanFilterTOAIMU: acceleration + its covariance */
+                    std::vector<double> acc((size_t)T_ * 3, 0.0), cov((size_t)T_ * 9, 0.0);
+                    for (int t = 0; t < T_; ++t) cov[(size_t)t * 9] = cov[(size_t)t * 9 + 4] = cov[(size_t)t * 9 + 8] = 1.0;
+                    for (const Pending &p : round) {
+                        if (p.kind != kind) continue;
+                        std::copy(p.err.begin() + 12, p.err.begin() + 15, acc.begin() + (size_t)p.row * 3);
+                        std::copy(p.err.begin() + 15, p.err.begin() + 24, cov.begin() + (size_t)p.row * 9);
+                    }
+                    if (real_ == 4) {
+                        std::vector<float> a32(acc.begin(), acc.end()), c32(cov.begin(), cov.end());
+                        check(kfpos_step_imu(h_, a32.data(), c32.data(), dt.data(), T_, nullptr), "kfpos_step_imu");
+                    } else {
+                        check(kfpos_step_imu(h_, acc.data(), cov.data(), dt.data(), T_, nullptr), "kfpos_step_imu");
+                    }
+                }
+            }
         }
         return calls;
     }

@@ -160,7 +160,10 @@ struct EpochAssembler {
 
 /* Batched mode (tagIds:=...): every listed tag gets a row of ONE GPU handle; messages go through
  * kfpos_ingest.h's BatchedRangingNode, 'F'/'P' lines advance time (timers + GPU rounds), 'P' prints one
- * line per tag: "P <t> <tagId> <ok> <x> <y> <z> <cov00> <cov11> <cov22>". IMU lines are ignored here. */
+ * line per tag: "P <t> <tagId> <ok> <x> <y> <z> <cov00> <cov11> <cov22>". Sensor messages carry the tag they
+ * belong to (a multi-tag node has one sensor topic per vehicle): lower-case kinds with the hex tag id after the
+ * time stamp -- "j <t> <tag> ...", "x <t> <tag> ...", "c <t> <tag> <heading>", "g <t> <tag> <mx> <my> <mz>" --
+ * and the same subscription switches as the single-tag node. */
 static int run_batched(const NodeParams &p, const std::string &trace) {
     std::vector<int> tagIds;
     {
@@ -177,7 +180,8 @@ static int run_batched(const NodeParams &p, const std::string &trace) {
         if (node) return;
         kfpos_config c;
         std::memset(&c, 0, sizeof(c));
-        c.model = p.algorithm == "ALGORITHM_KF_TOA_IMU" ? KFPOS_MODEL_TOA_IMU : KFPOS_MODEL_TOA;
+        c.model = p.algorithm == "ALGORITHM_KF_TOA_IMU" ? KFPOS_MODEL_TOA_IMU
+                : p.algorithm == "ALGORITHM_KF" ? KFPOS_MODEL_PLANAR : KFPOS_MODEL_TOA;
         c.n_tags = T;
         c.max_anchors = (int)anchorIds.size();
         c.storage = KFPOS_STORE_F64;
@@ -190,9 +194,22 @@ static int run_batched(const NodeParams &p, const std::string &trace) {
         c.use_init_pos = fixed ? 1 : 0;
         c.init_pos[0] = p.initPositionX; c.init_pos[1] = p.initPositionY; c.init_pos[2] = p.initPositionZ;
         if (kfpos_create(&c, &h) != KFPOS_OK) throw std::runtime_error(std::string("kfpos_create: ") + kfpos_last_error());
+        if (c.model == KFPOS_MODEL_PLANAR) { /* KalmanFilter::init(): the five XML parameters, read once for the bank */
+            KalmanFilter loader(p.accelNoise, p.useStartPosition == 1 ? p.initAngle : 0.0, p.jolt, "configPos",
+                                "configPX4Flow", "configUWB", "configIMU", "configMAG");
+            loader.setParamSource(fileParamSource({{"configPos", p.configPos}, {"configPX4Flow", p.configPX4Flow},
+                                                   {"configUWB", p.configUWB}, {"configIMU", p.configIMU},
+                                                   {"configMAG", p.configMAG}}));
+            if (!loader.init()) throw std::runtime_error("init() failed: a config* XML parameter is missing or malformed");
+            if (kfpos_set_planar(h, &loader.configuration()) != KFPOS_OK)
+                throw std::runtime_error(std::string("kfpos_set_planar: ") + kfpos_last_error());
+        }
         kfpos_set_anchors(h, anchorXyz.data(), anchorIds.data(), (int)anchorIds.size());
         node.reset(new BatchedRangingNode(h, tagIds, anchorIds));
     };
+    const bool kf = p.algorithm == "ALGORITHM_KF"; /* which topics node_pos.cpp subscribes (:146-173) */
+    const bool subTOA = kf ? p.useTOA == 1 : true, subIMU = kf ? p.useIMU == 1 : p.algorithm == "ALGORITHM_KF_TOA_IMU";
+    const bool subPX4 = kf && p.usePX4Flow == 1, subMAG = kf && p.useMAG == 1;
     std::ifstream in(trace);
     std::string line;
     while (std::getline(in, line)) {
@@ -205,11 +222,34 @@ static int run_batched(const NodeParams &p, const std::string &trace) {
             ss >> id >> x >> y >> z;
             anchorIds.push_back(id);
             anchorXyz.push_back(x); anchorXyz.push_back(y); anchorXyz.push_back(z);
-        } else if (kind == 'R') {
+        } else if (kind == 'R' && subTOA) {
             int anchorId, tag, seq; double t, mm, e;
             ss >> t >> anchorId >> tag >> mm >> seq >> e;
             ensure();
             node->onRanging(t, anchorId, tag, mm, e, seq);
+        } else if (kind == 'j' && subIMU) {
+            double t, w[3], cw[9], a[3], ca[9]; std::string tag;
+            ss >> t >> tag >> w[0] >> w[1] >> w[2];
+            for (double &v : cw) ss >> v;
+            ss >> a[0] >> a[1] >> a[2];
+            for (double &v : ca) ss >> v;
+            ensure();
+            node->onImu(t, (int)strtol(tag.c_str(), nullptr, 16), w, cw, a, ca);
+        } else if (kind == 'x' && subPX4) {
+            double t, ix, iy, iz, us; int q; std::string tag;
+            ss >> t >> tag >> ix >> iy >> iz >> us >> q;
+            ensure();
+            node->onPX4Flow(t, (int)strtol(tag.c_str(), nullptr, 16), ix, iy, iz, us, q);
+        } else if (kind == 'c' && subMAG) {
+            double t, heading; std::string tag;
+            ss >> t >> tag >> heading;
+            ensure();
+            node->onCompass(t, (int)strtol(tag.c_str(), nullptr, 16), heading);
+        } else if (kind == 'g' && subMAG) {
+            double t, m[3]; std::string tag;
+            ss >> t >> tag >> m[0] >> m[1] >> m[2];
+            ensure();
+            node->onMag(t, (int)strtol(tag.c_str(), nullptr, 16), m);
         } else if (kind == 'F') {
             double t; ss >> t;
             ensure();
