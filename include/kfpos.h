@@ -208,6 +208,14 @@ int kfpos_get_predicted(kfpos_handle *h, const double *dt_ahead, int32_t dt_len,
 int kfpos_state_dim(const kfpos_handle *h);
 int kfpos_get_state(kfpos_handle *h, double *x, double *P, uint32_t *flags);
 int kfpos_set_state(kfpos_handle *h, const double *x, const double *P, const uint32_t *flags);
+/* The latched sensor samples (lastImuMeasurement etc.), the rest of a checkpoint: n_tags x kfpos_latch_dim() doubles.
+ * 9-state: 12 = linearAcceleration[3] + its covariance 3x3 row-major (KalmanFilterTOAIMU.h:58-59); planar: 15 =
+ * PX4Flow {vx, vy, gyroz, covarianceVelocity, covarianceGyroZ}, IMU {ax, ay, angularVelocityZ,
+ * covarianceAccelerationXY[4], covarianceAngularVelocityZ}, magnetometer {angle, covarianceMag}
+ * (sensor_types.h:32-60); other models: 0, both calls are no-ops. Which samples are live is in the flags word. */
+int kfpos_latch_dim(const kfpos_handle *h);
+int kfpos_get_latch(kfpos_handle *h, double *latch);
+int kfpos_set_latch(kfpos_handle *h, const double *latch);
 
 /* ---- asynchronous device-buffer API (inputs already resident in HBM) ----
  * All pointers are device pointers; `stream` is a hipStream_t (NULL = the default stream). Calls

@@ -32,6 +32,7 @@ EXPORTS = [
     "kfpos_step_toa_imu_dev", "kfpos_get_pose_dev", "kfpos_run_trace_dev", "kfpos_last_error",
     "kfpos_strerror", "kfpos_version", "kfpos_timing_begin", "kfpos_timing_end",
     "kfpos_set_planar", "kfpos_step_sensor", "kfpos_step_sensor_dev", "kfpos_get_height",
+    "kfpos_latch_dim", "kfpos_get_latch", "kfpos_set_latch",
 ]
 
 
@@ -100,6 +101,9 @@ def load():
     L.kfpos_step_sensor.argtypes = [vp, i32, vp, vp, i32, vp]
     L.kfpos_step_sensor_dev.argtypes = [vp, i32, vp, vp, f64, vp, vp]
     L.kfpos_get_height.argtypes = [vp, vp]
+    L.kfpos_latch_dim.argtypes = [vp]
+    L.kfpos_get_latch.argtypes = [vp, vp]
+    L.kfpos_set_latch.argtypes = [vp, vp]
     L.kfpos_timing_begin.argtypes = [vp, vp]
     L.kfpos_timing_end.argtypes = [vp, vp, C.POINTER(C.c_float)]
     L.kfpos_last_error.restype = C.c_char_p
@@ -273,6 +277,17 @@ class KfposBank:
         fl = None if flags is None else np.ascontiguousarray(flags, dtype=np.uint32)
         self._chk(self.lib.kfpos_set_state(self._h, x.ctypes.data, P.ctypes.data,
                                            None if fl is None else fl.ctypes.data))
+
+    def get_latch(self):
+        """Latched sensor samples (T, kfpos_latch_dim): with get_state() a complete checkpoint."""
+        out = np.zeros((self.T, self.lib.kfpos_latch_dim(self._h)))
+        self._chk(self.lib.kfpos_get_latch(self._h, out.ctypes.data if out.size else None))
+        return out
+
+    def set_latch(self, latch):
+        a = np.ascontiguousarray(latch, dtype=np.float64)
+        assert a.shape == (self.T, self.lib.kfpos_latch_dim(self._h))
+        self._chk(self.lib.kfpos_set_latch(self._h, a.ctypes.data if a.size else None))
 
     # ---- device-buffer API (pointers: ints or torch tensors; layouts in include/kfpos.h) ----
     def step_toa_dev(self, range_mm, err_est, dt, status=None, stream=None, dt_dev=None):

@@ -1520,6 +1520,58 @@ int kfpos_set_state(kfpos_handle *h, const double *x, const double *P, const uin
     return KFPOS_OK;
 }
 
+int kfpos_latch_dim(const kfpos_handle *h) {
+    if (!h) return 0;
+    return h->cfg.model == KFPOS_MODEL_TOA_IMU ? 12 : (h->cfg.model == KFPOS_MODEL_PLANAR ? LATCH_ROWS : 0);
+}
+
+int kfpos_get_latch(kfpos_handle *h, double *latch) {
+    if (!h) return KFPOS_ERR_ARG;
+    const int L = kfpos_latch_dim(h);
+    if (L == 0) return KFPOS_OK;
+    if (!latch) return KFPOS_ERR_ARG;
+    HIPCHK(hipDeviceSynchronize());
+    const size_t T = h->cfg.n_tags;
+    if (L == LATCH_ROWS) return stage_out(h, latch, h->d_latch, LATCH_ROWS);
+    /* 9-state: acceleration [3][T] and the lower triangle {00,10,11,20,21,22} [6][T], kfpos_real */
+    std::vector<unsigned char> a(3 * T * h->msz), c(6 * T * h->msz);
+    HIPCHK(hipMemcpy(a.data(), h->d_imu_acc, a.size(), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(c.data(), h->d_imu_cov, c.size(), hipMemcpyDeviceToHost));
+    auto rd = [&](const std::vector<unsigned char> &b, size_t k) {
+        return h->msz == 4 ? (double)((const float *)b.data())[k] : ((const double *)b.data())[k];
+    };
+    static const int tri[3][3] = {{0, 1, 3}, {1, 2, 4}, {3, 4, 5}};
+    for (size_t t = 0; t < T; ++t) {
+        for (int k = 0; k < 3; ++k) latch[t * 12 + k] = rd(a, (size_t)k * T + t);
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) latch[t * 12 + 3 + 3 * i + j] = rd(c, (size_t)tri[i][j] * T + t);
+    }
+    return KFPOS_OK;
+}
+
+int kfpos_set_latch(kfpos_handle *h, const double *latch) {
+    if (!h) return KFPOS_ERR_ARG;
+    const int L = kfpos_latch_dim(h);
+    if (L == 0) return KFPOS_OK;
+    if (!latch) return KFPOS_ERR_ARG;
+    HIPCHK(hipDeviceSynchronize());
+    const size_t T = h->cfg.n_tags;
+    if (L == LATCH_ROWS) return stage_in(h, h->d_latch, latch, LATCH_ROWS, sizeof(double));
+    std::vector<unsigned char> a(3 * T * h->msz), c(6 * T * h->msz);
+    auto wr = [&](std::vector<unsigned char> &b, size_t k, double v) {
+        if (h->msz == 4) ((float *)b.data())[k] = (float)v;
+        else ((double *)b.data())[k] = v;
+    };
+    static const int li[6] = {0, 1, 1, 2, 2, 2}, lj[6] = {0, 0, 1, 0, 1, 2};
+    for (size_t t = 0; t < T; ++t) {
+        for (int k = 0; k < 3; ++k) wr(a, (size_t)k * T + t, latch[t * 12 + k]);
+        for (int k = 0; k < 6; ++k) wr(c, (size_t)k * T + t, latch[t * 12 + 3 + 3 * li[k] + lj[k]]);
+    }
+    HIPCHK(hipMemcpy(h->d_imu_acc, a.data(), a.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_imu_cov, c.data(), c.size(), hipMemcpyHostToDevice));
+    return KFPOS_OK;
+}
+
 int kfpos_timing_begin(kfpos_handle *h, void *stream) {
     if (!h) return KFPOS_ERR_ARG;
     HIPCHK(hipEventRecord(h->ev0, (hipStream_t)stream));
