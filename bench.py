@@ -206,6 +206,17 @@ def main():
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        # what actually bounds the step kernel: fp64 VALU issue (committed PMC summary of this same command)
+        valu = None
+        ppath = os.path.join(ROOT, "profiles", "r01g_pmc_sq_counters.json")
+        if os.path.exists(ppath):
+            try:
+                c = next(v for k, v in json.load(open(ppath)).items() if "k_step_imu9" in k)
+                valu = {"busy_frac": c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"],
+                        "fp64_instr_per_wave_epoch": c["SQ_INSTS_VALU"] / c["SQ_WAVES"] / 25,
+                        "source": "profiles/r01g_pmc_sq_counters.json (rocprofv3 --pmc, 25 epochs per launch)"}
+            except Exception:
+                valu = None
         out = {
             "metric": "EKF predict+update steps/s at 65536 tags x 8 anchors; RMS pos err vs CPU ref",
             "value": value, "unit": "tag-steps/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -221,7 +232,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_step_imu9<double,float,8>", "kernel_us_per_launch": per_launch_s * 1e6,
                          "units_per_launch": units_per_launch,
-                         "algorithmic_bytes_per_tag_step": ALGO_BYTES_PER_TAG_STEP},
+                         "algorithmic_bytes_per_tag_step": ALGO_BYTES_PER_TAG_STEP,
+                         "valu": valu},
             "state_finite": finite, "trajectory_matches_state": traj_ok, "rms_vs_truth_m": track_rms,
         }
         if per_epoch is not None:
