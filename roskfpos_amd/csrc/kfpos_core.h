@@ -307,7 +307,7 @@ KFPOS_FN void ml_sweep(const double p[3], const SC &sc, const Params &pr, uint64
          * missing range never enters), which keeps the unrolled anchors in one basic block and lets the
          * scheduler interleave their independent rsqrt chains */
         const bool on = used(sc, a, drop);
-        const double r = sc.R(a), w = on ? sc.W(a) : 0.0;
+        const double r = sc.R(a), w = sc.W(a); /* 0 for an absent / dropped range (set_weights_*) */
         const double dx = pr.anchors[3 * a] - p[0], dy = pr.anchors[3 * a + 1] - p[1],
                      dz = pr.anchors[3 * a + 2] - p[2];
         double d, invd;
@@ -412,13 +412,17 @@ KFPOS_FN bool ml_covariance_throws(const SC &sc, const Params &pr, uint64_t drop
     return bad;
 }
 
+/* Working weights. An absent or dropped range gets weight 0 HERE (a select, so a garbage errorEstimation of a
+ * missing range never enters): the sweeps, which run 10-60 times per step, then read the weight as it is. */
 template <class SC>
-KFPOS_FN void set_weights_ml(SC &sc, const Params &pr) {
-    for_anchors<SC>(pr, [&](int a) { sc.setW(a, kf_rcp(sc.E(a))); });
+KFPOS_FN void set_weights_ml(SC &sc, const Params &pr, uint64_t drop) {
+    for_anchors<SC>(pr, [&](int a) { sc.setW(a, used(sc, a, drop) ? kf_rcp(sc.E(a)) : 0.0); });
 }
 template <class SC>
-KFPOS_FN void set_weights_iekf(SC &sc, const Params &pr, double e_ml) {
-    for_anchors<SC>(pr, [&](int a) { sc.setW(a, kf_rcp(stdmax(e_ml, sc.E(a)))); }); /* KalmanFilterTOA.cpp:281 */
+KFPOS_FN void set_weights_iekf(SC &sc, const Params &pr, double e_ml, uint64_t drop) {
+    for_anchors<SC>(pr, [&](int a) { /* KalmanFilterTOA.cpp:281 */
+        sc.setW(a, used(sc, a, drop) ? kf_rcp(stdmax(e_ml, sc.E(a))) : 0.0);
+    });
 }
 
 /* Top-N composition (BASELINE config 5; MLLocation.cpp:284-300, 325-339): rank the residual^2
@@ -428,7 +432,7 @@ KFPOS_FN uint64_t topn_mask(const double seed[3], SC &sc, const Params &pr, int 
     int ndrop = n_valid - 4 < pr.top_n ? n_valid - 4 : pr.top_n;
     if (ndrop <= 0) return 0;
     double p[3] = {seed[0], seed[1], seed[2]}, sse;
-    set_weights_ml(sc, pr);
+    set_weights_ml(sc, pr, 0ull);
     ml_estimate(p, sc, pr, 0, n_valid, sse);
     uint64_t drop = 0;
     for (int k = 0; k < ndrop; ++k) {
@@ -472,7 +476,7 @@ KFPOS_FN uint32_t step_ml(double pos[3], double cov[6], SC &sc, const Params &pr
         n_valid = count_used(sc, pr, drop);
     }
     double p[3] = {seed[0], seed[1], seed[2]}, sse;
-    set_weights_ml(sc, pr);
+    set_weights_ml(sc, pr, drop);
     const int it = ml_estimate(p, sc, pr, drop, n_valid, sse);
     if (ml_covariance_throws(sc, pr, drop, n_valid, sse)) return ST_UPDATE_SKIPPED;
     double c[6];
@@ -554,14 +558,14 @@ KFPOS_FN void iekf6_weights(const double xhat_p[3], SC &sc, const Params &pr, ui
                             Iekf6Out &o) {
     o.flags = (n_used < 4) ? ST_FEW_RANGES : 0u;
     double pml[3] = {xhat_p[0], xhat_p[1], xhat_p[2]}, e_ml;
-    set_weights_ml(sc, pr);
+    set_weights_ml(sc, pr, drop);
     o.ml_iters = ml_estimate(pml, sc, pr, drop, n_used, e_ml);
     if (ml_covariance_throws(sc, pr, drop, n_used, e_ml)) o.flags |= ST_UPDATE_SKIPPED;
     if (isnan(pml[0]) || isnan(pml[1]) || isnan(pml[2])) {
         o.flags |= ST_ML_FALLBACK;
         e_ml = (n_used == 0) ? -1.0 : ml_sse(xhat_p, sc, pr, drop);
     }
-    set_weights_iekf(sc, pr, e_ml);
+    set_weights_iekf(sc, pr, e_ml, drop);
 }
 
 /* Second half (KalmanFilterTOA.cpp:285-324): the IEKF loop, up to, not including, the covariance
@@ -583,16 +587,19 @@ KFPOS_FN void iekf6(const double xhat_p[3], const Cov<6, SYMM> &P, SC &sc,
                          dz = p[2] - pr.anchors[3 * a + 2];
             double d, invd;
             kf_sqrt_rsqrt_sweep(dx * dx + dy * dy + dz * dz, d, invd);
-            const double w = used(sc, a, drop) ? sc.W(a) : 0.0, y = sc.R(a) - d; /* branch-free, see ml_sweep */
-            c += y * y * w;
+            const double w = sc.W(a), y = sc.R(a) - d; /* weight 0 = absent / dropped range (set_weights_iekf) */
+            const double yw = y * w;
+            c += y * yw;
             const double gx = dx * invd, gy = dy * invd, gz = dz * invd;
-            const double v = (y - (gx * dp[0] + gy * dp[1] + gz * dp[2])) * w;
-            u0 += gx * v; u1 += gy * v; u2 += gz * v;
+            u0 += gx * yw; u1 += gy * yw; u2 += gz * yw;
             const double wx = w * gx, wy = w * gy, wz = w * gz;
             m0 += wx * gx; m1 += wx * gy; m2 += wx * gz;
             m3 += wy * gy; m4 += wy * gz; m5 += wz * gz;
         });
-        const double m[6] = {m0, m1, m2, m3, m4, m5}, u[3] = {u0, u1, u2};
+        /* u = G' R^-1 (y - G delta) = G' R^-1 y - M delta: the delta term once per pass, not once per anchor */
+        const double m[6] = {m0, m1, m2, m3, m4, m5},
+                     u[3] = {u0 - (m0 * dp[0] + m1 * dp[1] + m2 * dp[2]), u1 - (m1 * dp[0] + m3 * dp[1] + m4 * dp[2]),
+                             u2 - (m2 * dp[0] + m4 * dp[1] + m5 * dp[2])};
         if (fabs(cost - c) / cost < tol) break; /* KalmanFilterTOA.cpp:307 */
         cost = c;
         KFPOS_UNROLL
@@ -671,7 +678,7 @@ KFPOS_FN uint32_t step_toa6(Tag6<SYMM> &tg, SC &sc, const Params &pr, double dt)
         /* ML initialisation, KalmanFilterTOA.cpp:90-108 (only the COV_FULL layout gets here) */
         if (n_valid < 4) return ST_FEW_RANGES;
         double p[3] = {1.0, 1.0, 4.0}, sse, c[6];
-        set_weights_ml(sc, pr);
+        set_weights_ml(sc, pr, 0ull);
         const int it = ml_estimate(p, sc, pr, 0, n_valid, sse);
         if (ml_covariance_throws(sc, pr, 0, n_valid, sse)) return ST_UPDATE_SKIPPED; /* reference: abort */
         ml_covariance(p, sc, pr, sse, c);
@@ -907,10 +914,10 @@ KFPOS_FN void iekf9_weights(const double xhat[9], SC &sc, const Params &pr, bool
     o.ml_iters = 0;
     if (has_ranging) {
         double pml[3] = {xhat[0], xhat[1], xhat[2]}, e_ml;
-        set_weights_ml(sc, pr);
+        set_weights_ml(sc, pr, 0ull);
         o.ml_iters = ml_estimate(pml, sc, pr, 0ull, n_used, e_ml); /* no NaN fallback in this filter */
         if (ml_covariance_throws(sc, pr, 0ull, n_used, e_ml)) o.flags |= ST_UPDATE_SKIPPED;
-        set_weights_iekf(sc, pr, e_ml);
+        set_weights_iekf(sc, pr, e_ml, 0ull);
     }
 }
 
@@ -935,17 +942,20 @@ KFPOS_FN void iekf9(const double xhat[9], const Cov<9, true> &P, SC &sc, const P
                              dz = p[2] - pr.anchors[3 * a + 2];
                 double d, invd;
                 kf_sqrt_rsqrt_sweep(dx * dx + dy * dy + dz * dz, d, invd);
-                const double w = used(sc, a, drop) ? sc.W(a) : 0.0, y = sc.R(a) - d; /* branch-free, see ml_sweep */
-                c += y * y * w;
+                const double w = sc.W(a), y = sc.R(a) - d; /* weight 0 = absent / dropped range (set_weights_iekf) */
+                const double yw = y * w;
+                c += y * yw;
                 const double gx = dx * invd, gy = dy * invd, gz = dz * invd;
-                const double v = (y - (gx * de[0] + gy * de[1] + gz * de[2])) * w;
-                u0 += gx * v; u1 += gy * v; u2 += gz * v;
+                u0 += gx * yw; u1 += gy * yw; u2 += gz * yw;
                 const double wx = w * gx, wy = w * gy, wz = w * gz;
                 m0 += wx * gx; m1 += wx * gy; m2 += wx * gz;
                 m3 += wy * gy; m4 += wy * gz; m5 += wz * gz;
             });
         }
-        const double m[6] = {m0, m1, m2, m3, m4, m5}, u[3] = {u0, u1, u2};
+        /* u_r = G' R^-1 (y - G delta_p) = G' R^-1 y - M_r delta_p: the delta term once per pass */
+        const double m[6] = {m0, m1, m2, m3, m4, m5},
+                     u[3] = {u0 - (m0 * de[0] + m1 * de[1] + m2 * de[2]), u1 - (m1 * de[0] + m3 * de[1] + m4 * de[2]),
+                             u2 - (m2 * de[0] + m4 * de[1] + m5 * de[2])};
         /* IMU rows: y_a = z_a - a, cost += y_a' Sigma^-1 y_a, u_a = D Sigma^-1 (y_a - D delta_a),
          * M_a = D Sigma^-1 D with D = diag(a) (sic, KalmanFilterTOAIMU.cpp:441-473) */
         double ua[3] = {0, 0, 0}, ma[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
@@ -1077,7 +1087,7 @@ KFPOS_FN uint32_t step_imu9(Tag9 &tg, SC &sc, const Params &pr, double dt,
         if (!has_ranging) return 0;
         if (n_valid < 4) return ST_FEW_RANGES;
         double p[3] = {1.0, 1.0, 4.0}, sse, c[6];
-        set_weights_ml(sc, pr);
+        set_weights_ml(sc, pr, 0ull);
         const int it = ml_estimate(p, sc, pr, 0, n_valid, sse);
         if (ml_covariance_throws(sc, pr, 0, n_valid, sse)) return ST_UPDATE_SKIPPED; /* reference: abort */
         ml_covariance(p, sc, pr, sse, c);
@@ -1214,7 +1224,7 @@ KFPOS_FN void ml2d_sweep(const double p[2], double z, const SC &sc, const Params
     double sse_ = 0.0, g0 = 0.0, g1 = 0.0, h0 = 0.0, h1 = 0.0, h3 = 0.0;
     for_anchors<SC>(pr, [&](int a) {
         const bool on = used(sc, a, 0);
-        const double r = sc.R(a), w = on ? sc.W(a) : 0.0;
+        const double r = sc.R(a), w = sc.W(a); /* 0 for an absent / dropped range (set_weights_*) */
         const double dx = pr.anchors[3 * a] - p[0], dy = pr.anchors[3 * a + 1] - p[1], dz = pr.anchors[3 * a + 2] - z;
         double d, invd;
         kf_sqrt_rsqrt_sweep(dx * dx + dy * dy + dz * dz, d, invd);
@@ -1348,10 +1358,10 @@ template <class SC>
 KFPOS_FN void iekf8_weights(const double xhat[8], double z, SC &sc, const Params &pr, int n_used, Iekf8Out &o) {
     o.flags = (n_used < 3) ? ST_FEW_RANGES : 0u;
     double pml[2] = {xhat[0], xhat[1]}, e_ml;
-    set_weights_ml(sc, pr);
+    set_weights_ml(sc, pr, 0ull);
     o.ml_iters = ml2d_estimate(pml, z, sc, pr, n_used, e_ml);
     if (ml_covariance_throws(sc, pr, 0ull, n_used, e_ml, 3)) o.flags |= ST_UPDATE_SKIPPED;
-    set_weights_iekf(sc, pr, e_ml);
+    set_weights_iekf(sc, pr, e_ml, 0ull);
 }
 
 /* kalmanStep3D second part (KalmanFilter.cpp:444-500). rows: which row groups this call carries. With
@@ -1381,14 +1391,17 @@ KFPOS_FN void iekf8(const double xhat[8], double z, const PM &P, Cov<8, true> &P
                 const double dx = x[0] - pr.anchors[3 * a], dy = x[1] - pr.anchors[3 * a + 1], dz = z - pr.anchors[3 * a + 2];
                 double d, invd;
                 kf_sqrt_rsqrt_sweep(dx * dx + dy * dy + dz * dz, d, invd);
-                const double w = used(sc, a, drop) ? sc.W(a) : 0.0, y = sc.R(a) - d;
-                c += y * y * w;
+                const double w = sc.W(a), y = sc.R(a) - d; /* weight 0 = absent range (set_weights_iekf) */
+                const double yw = y * w;
+                c += y * yw;
                 const double gx = dx * invd, gy = dy * invd;
-                const double v = (y + (gx * dl[0] + gy * dl[1])) * w; /* y - G delta, delta = -dl */
-                u0 += gx * v; u1 += gy * v;
+                u0 += gx * yw; u1 += gy * yw;
                 const double wx = w * gx, wy = w * gy;
                 m0 += wx * gx; m1 += wx * gy; m3 += wy * gy;
             });
+            /* u = G' R^-1 (y - G delta) with delta = -dl: G' R^-1 y + M dl, the delta term once per pass */
+            u0 += m0 * dl[0] + m1 * dl[1];
+            u1 += m1 * dl[0] + m3 * dl[1];
         }
         /* sensor rows at the current linearisation point */
         double sn = 0.0, cs = 1.0, sw = 0.0, cw = 1.0;
@@ -1527,7 +1540,7 @@ KFPOS_FN uint32_t step_planar8(Tag8 &tg, SC &sc, const Params &pr, double dt, ui
         if (!has_r) return 0;
         int it;
         double c00, c01, c11;
-        set_weights_ml(sc, pr);
+        set_weights_ml(sc, pr, 0ull);
         if (pr.use_fixed_height) {
             if (n_valid < 3) return ST_FEW_RANGES; /* the reference indexes an empty covariance here: abort */
             double p[2] = {1.0, 1.0}, sse, c[3];
