@@ -715,6 +715,23 @@ __global__ __launch_bounds__(WAVE) void k_get_pose(const PoseArgs a) {
     if (a.status) a.status[t] = s;
 }
 
+/* ------------------------------------------------------------------ layout kernels of the host-buffer API */
+/* The host API takes and returns row-major [tag][component] arrays (one row per reference call); the step kernels
+ * want [component][tag]. The turn is done on the device, next to one plain copy per array, instead of element by
+ * element on the CPU. E = 4- or 8-byte element. */
+template <typename E>
+__global__ __launch_bounds__(256) void k_rows_to_cols(const E *src, E *dst, int T, int C) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (size_t)T) return;
+    for (int c = 0; c < C; ++c) dst[(size_t)c * T + t] = src[t * C + c];
+}
+template <typename E>
+__global__ __launch_bounds__(256) void k_cols_to_rows(const E *src, E *dst, int T, int C) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (size_t)T) return;
+    for (int c = 0; c < C; ++c) dst[t * C + c] = src[(size_t)c * T + t];
+}
+
 /* ------------------------------------------------------------------ host side */
 thread_local std::string g_err;
 
@@ -757,6 +774,9 @@ struct kfpos_handle {
     bool planar_sensors = false; /* a PX4Flow / IMU / magnetometer / compass sample has been fed: latches are live */
     double *d_latch = nullptr;   /* [15][T] */
     double *d_sensor = nullptr;  /* [24][T] staging of one sensor sample */
+    /* row-major staging area of the host-buffer API: one region per array of a call (bump-allocated) */
+    unsigned char *d_stage = nullptr;
+    size_t stage_cap = 0, stage_used = 0;
 };
 
 namespace {
@@ -888,23 +908,57 @@ int launch_step(kfpos_handle *h, const KArgs &a, hipStream_t s) {
     return KFPOS_OK;
 }
 
-/* host row-major [T][C] -> staged component-major [C][T] of `esz`-byte elements */
+/* a region of the row-major staging area; regions live until the next stage_reset() (start of an API call) */
+int stage_region(kfpos_handle *h, size_t bytes, void **out) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (h->stage_used + bytes > h->stage_cap) {
+        /* grow: everything queued so far still reads the old buffer, so drain first */
+        HIPCHK(hipDeviceSynchronize());
+        const size_t cap = (h->stage_used + bytes) * 2;
+        unsigned char *nb = nullptr;
+        HIPCHK(hipMalloc((void **)&nb, cap));
+        if (h->d_stage) (void)hipFree(h->d_stage);
+        h->d_stage = nb;
+        h->stage_cap = cap;
+        h->stage_used = 0; /* regions handed out before the growth have been consumed (synchronised above) */
+    }
+    *out = h->d_stage + h->stage_used;
+    h->stage_used += bytes;
+    return KFPOS_OK;
+}
+void stage_reset(kfpos_handle *h) { h->stage_used = 0; }
+
+/* host row-major [T][C] -> component-major [C][T] of `esz`-byte elements: one copy + a device-side turn */
 int stage_in(kfpos_handle *h, void *dst, const void *src, int C, size_t esz) {
     const size_t T = h->cfg.n_tags;
-    std::vector<unsigned char> tmp(T * C * esz);
-    const unsigned char *s = (const unsigned char *)src;
-    for (size_t t = 0; t < T; ++t)
-        for (int c = 0; c < C; ++c) std::memcpy(&tmp[((size_t)c * T + t) * esz], &s[(t * C + c) * esz], esz);
-    HIPCHK(hipMemcpy(dst, tmp.data(), tmp.size(), hipMemcpyHostToDevice));
+    if (C == 1) {
+        HIPCHK(hipMemcpy(dst, src, T * esz, hipMemcpyHostToDevice));
+        return KFPOS_OK;
+    }
+    void *rows = nullptr;
+    const int rc = stage_region(h, T * C * esz, &rows);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(rows, src, T * C * esz, hipMemcpyHostToDevice));
+    const int blocks = (int)((T + 255) / 256);
+    if (esz == 4) hipLaunchKernelGGL(k_rows_to_cols<uint32_t>, dim3(blocks), dim3(256), 0, 0, (const uint32_t *)rows, (uint32_t *)dst, (int)T, C);
+    else hipLaunchKernelGGL(k_rows_to_cols<uint64_t>, dim3(blocks), dim3(256), 0, 0, (const uint64_t *)rows, (uint64_t *)dst, (int)T, C);
+    HIPCHK(hipGetLastError());
     return KFPOS_OK;
 }
 /* device [C][T] doubles -> host row-major [T][C] */
 int stage_out(kfpos_handle *h, double *dst, const double *dsrc, int C) {
     const size_t T = h->cfg.n_tags;
-    std::vector<double> tmp(T * C);
-    HIPCHK(hipMemcpy(tmp.data(), dsrc, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
-    for (size_t t = 0; t < T; ++t)
-        for (int c = 0; c < C; ++c) dst[t * C + c] = tmp[(size_t)c * T + t];
+    if (C == 1) {
+        HIPCHK(hipMemcpy(dst, dsrc, T * sizeof(double), hipMemcpyDeviceToHost));
+        return KFPOS_OK;
+    }
+    void *rows = nullptr;
+    const int rc = stage_region(h, T * C * sizeof(double), &rows);
+    if (rc) return rc;
+    const int blocks = (int)((T + 255) / 256);
+    hipLaunchKernelGGL(k_cols_to_rows<uint64_t>, dim3(blocks), dim3(256), 0, 0, (const uint64_t *)dsrc, (uint64_t *)rows, (int)T, C);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(dst, rows, T * C * sizeof(double), hipMemcpyDeviceToHost));
     return KFPOS_OK;
 }
 
@@ -1068,7 +1122,8 @@ int kfpos_create(const kfpos_config *cfg, kfpos_handle **out) {
 int kfpos_destroy(kfpos_handle *h) {
     if (!h) return KFPOS_ERR_ARG;
     void *ptrs[] = {h->d_pos, h->d_vel, h->d_P, h->d_imu_acc, h->d_imu_cov, h->d_flags, h->d_ranges,
-                    h->d_err, h->d_accel, h->d_cov, h->d_dt, h->d_out, h->d_status, h->d_latch, h->d_sensor};
+                    h->d_err, h->d_accel, h->d_cov, h->d_dt, h->d_out, h->d_status, h->d_latch, h->d_sensor,
+                    h->d_stage};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -1092,6 +1147,7 @@ int kfpos_set_anchors(kfpos_handle *h, const double *xyz, const int32_t *ids, in
 int kfpos_set_init_positions(kfpos_handle *h, const double *xyz) {
     if (!h || !xyz) return KFPOS_ERR_ARG;
     if (!h->cfg.use_init_pos || h->stepped) return KFPOS_ERR_STATE;
+    stage_reset(h);
     if (h->n == 3) { /* ALGORITHM_ML: the seed of every solve */
         const int rc = stage_in(h, h->d_vel, xyz, 3, sizeof(double));
         if (rc) return rc;
@@ -1295,6 +1351,7 @@ int kfpos_step_toa(kfpos_handle *h, const int32_t *range_mm, const void *err_est
                    int32_t dt_len, uint32_t *status) {
     if (!h || !range_mm || !err_est) return KFPOS_ERR_ARG;
     if (!h->have_anchors) return KFPOS_ERR_STATE;
+    stage_reset(h);
     const double *d_dt;
     double shared;
     int rc = stage_dt(h, dt, dt_len, &d_dt, &shared);
@@ -1313,6 +1370,7 @@ int kfpos_step_imu(kfpos_handle *h, const void *accel, const void *cov, const do
         return KFPOS_OK;
     }
     const double *d_dt;
+    stage_reset(h);
     double shared;
     int rc = stage_dt(h, dt, dt_len, &d_dt, &shared);
     if (rc) return rc;
@@ -1331,6 +1389,7 @@ int kfpos_step_sensor(kfpos_handle *h, int32_t kind, const double *data, const d
         return KFPOS_OK;
     }
     const double *d_dt;
+    stage_reset(h);
     double shared;
     int rc = stage_dt(h, dt, dt_len, &d_dt, &shared);
     if (rc) return rc;
@@ -1352,6 +1411,7 @@ int kfpos_step_toa_imu(kfpos_handle *h, const int32_t *range_mm, const void *err
     if (!h || !range_mm || !err_est || !accel || !cov) return KFPOS_ERR_ARG;
     if (h->cfg.model != KFPOS_MODEL_TOA_IMU) return KFPOS_ERR_MODEL;
     if (!h->have_anchors) return KFPOS_ERR_STATE;
+    stage_reset(h);
     const double *d_dt;
     double shared;
     int rc = stage_dt(h, dt, dt_len, &d_dt, &shared);
@@ -1369,6 +1429,7 @@ int kfpos_step_toa_imu(kfpos_handle *h, const int32_t *range_mm, const void *err
 static int get_pose_host(kfpos_handle *h, double dt_ahead, const double *dt_each, double *pos, double *cov3x3,
                          double *vel, uint32_t *status) {
     if (!h) return KFPOS_ERR_ARG;
+    stage_reset(h);
     const size_t T = h->cfg.n_tags;
     double *dp = h->d_out, *dc = h->d_out + 3 * T, *dv = h->d_out + 12 * T;
     const double *d_each = nullptr;
@@ -1400,6 +1461,7 @@ int kfpos_get_pose_each(kfpos_handle *h, const double *dt_ahead, double *pos, do
 int kfpos_get_predicted(kfpos_handle *h, const double *dt_ahead, int32_t dt_len, double *x, double *P,
                         uint32_t *status) {
     if (!h || !dt_ahead || !x || !P || (dt_len != 1 && dt_len != h->cfg.n_tags)) return KFPOS_ERR_ARG;
+    stage_reset(h);
     const size_t T = h->cfg.n_tags, n = h->n;
     double *dx = nullptr, *dP = nullptr;
     HIPCHK(hipMalloc((void **)&dx, n * T * sizeof(double)));
@@ -1531,6 +1593,7 @@ int kfpos_get_latch(kfpos_handle *h, double *latch) {
     if (L == 0) return KFPOS_OK;
     if (!latch) return KFPOS_ERR_ARG;
     HIPCHK(hipDeviceSynchronize());
+    stage_reset(h);
     const size_t T = h->cfg.n_tags;
     if (L == LATCH_ROWS) return stage_out(h, latch, h->d_latch, LATCH_ROWS);
     /* 9-state: acceleration [3][T] and the lower triangle {00,10,11,20,21,22} [6][T], kfpos_real */
@@ -1555,6 +1618,7 @@ int kfpos_set_latch(kfpos_handle *h, const double *latch) {
     if (L == 0) return KFPOS_OK;
     if (!latch) return KFPOS_ERR_ARG;
     HIPCHK(hipDeviceSynchronize());
+    stage_reset(h);
     const size_t T = h->cfg.n_tags;
     if (L == LATCH_ROWS) return stage_in(h, h->d_latch, latch, LATCH_ROWS, sizeof(double));
     std::vector<unsigned char> a(3 * T * h->msz), c(6 * T * h->msz);
