@@ -195,6 +195,56 @@ KFPOS_FN double gen3_adjugate(const double m[9], double adj[9]) {
     return m[0] * adj[0] + m[1] * adj[3] + m[2] * adj[6];
 }
 
+/* X = A^-1 B for a general N x N A (row-major) and K right-hand sides (B, X: N x K row-major) by Gaussian
+ * elimination with partial pivoting, branch-free (rows are exchanged through selects, every index is static). The
+ * adjugates above lose digits when the eigenvalues of I + M P spread over many decades (determinant by
+ * cancellation): a prior covariance of 1e4 m^2 against range variances of 1e-3 m^2 -- an ML initialisation from
+ * coplanar anchors -- costs them 11 of 16. Used only for such steps (illconditioned()). */
+template <int N, int K>
+KFPOS_FN void gauss_solve(const double *a, const double *b, double *x) {
+    double r[N][N + K];
+    KFPOS_UNROLL
+    for (int i = 0; i < N; ++i) {
+        KFPOS_UNROLL
+        for (int j = 0; j < N; ++j) r[i][j] = a[N * i + j];
+        KFPOS_UNROLL
+        for (int k = 0; k < K; ++k) r[i][N + k] = b[K * i + k];
+    }
+    KFPOS_UNROLL
+    for (int c = 0; c < N; ++c) {
+        KFPOS_UNROLL
+        for (int i = c + 1; i < N; ++i) { /* largest |entry| of column c to row c */
+            const bool sw = fabs(r[i][c]) > fabs(r[c][c]);
+            KFPOS_UNROLL
+            for (int k = c; k < N + K; ++k) {
+                const double tc = r[c][k], ti = r[i][k];
+                r[c][k] = sw ? ti : tc;
+                r[i][k] = sw ? tc : ti;
+            }
+        }
+        const double ip = 1.0 / r[c][c];
+        KFPOS_UNROLL
+        for (int i = c + 1; i < N; ++i) {
+            const double f = r[i][c] * ip;
+            KFPOS_UNROLL
+            for (int k = c + 1; k < N + K; ++k) r[i][k] -= f * r[c][k];
+        }
+    }
+    KFPOS_UNROLL
+    for (int k = 0; k < K; ++k) {
+        double sol[N];
+        KFPOS_UNROLL
+        for (int i = N - 1; i >= 0; --i) {
+            double v = r[i][N + k];
+            KFPOS_UNROLL
+            for (int j = i + 1; j < N; ++j) v -= r[i][j] * sol[j];
+            sol[i] = v / r[i][i];
+        }
+        KFPOS_UNROLL
+        for (int i = 0; i < N; ++i) x[K * i + k] = sol[i];
+    }
+}
+
 /* Lower Cholesky of a symmetric PSD 3x3 {00,01,02,11,12,22}; a pivot that cancels to
  * rounding level marks a rank-deficient direction (fewer than 3 independent ranges): its
  * column is zeroed, which is the semidefinite factor (M = L L' still holds).
@@ -380,7 +430,7 @@ KFPOS_FN int ml_estimate(double p[3], const SC &sc, const Params &pr, uint64_t d
 /* covariance of the ML estimate, inv(J' diag(max(e, e_ML))^-1 J) (MLLocation.cpp:229-252);
  * symmetric 3x3 packed. Only the ML initialisation uses it. */
 template <class SC>
-KFPOS_FN void ml_covariance(const double p[3], const SC &sc, const Params &pr, double sse,
+KFPOS_FN bool ml_covariance(const double p[3], const SC &sc, const Params &pr, double sse,
                                    double cov[6]) {
     double m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0, c[6];
     for_anchors<SC>(pr, [&](int a) {
@@ -394,9 +444,11 @@ KFPOS_FN void ml_covariance(const double p[3], const SC &sc, const Params &pr, d
         m3 += w * gy * gy; m4 += w * gy * gz; m5 += w * gz * gz;
     });
     const double m[6] = {m0, m1, m2, m3, m4, m5};
-    const double idet = 1.0 / sym3_cofactors(m, c);
+    const double det = sym3_cofactors(m, c);
+    const double idet = 1.0 / det;
     KFPOS_UNROLL
     for (int k = 0; k < 6; ++k) cov[k] = c[k] * idet;
+    return det != 0.0; /* inv() of an exactly singular J' W J throws (anchors and seed in one plane / on one line) */
 }
 
 /* MLLocation::estimatePosition ends with inv(diagmat(max(e_i, e_ML))) and inv(J' W J) (MLLocation.cpp:248-252).
@@ -412,6 +464,11 @@ KFPOS_FN bool ml_covariance_throws(const SC &sc, const Params &pr, uint64_t drop
     return bad;
 }
 
+/* Not detected in the per-epoch solves: the second inverse, inv(J' W J), also throws when J' W J is EXACTLY singular
+ * (all used anchors and the estimate on one line / in one plane with coordinates symmetric enough that every
+ * cancellation is exact -- anchors at (0,0) and (10,10) with the estimate on the diagonal). The update path does not
+ * form that covariance (an extra sweep per solve, 3-14 % of a step, for a measure-zero geometry); the ML
+ * initialisation, which needs the covariance anyway, does report it (ml_covariance / ml2d_covariance). */
 /* Working weights. An absent or dropped range gets weight 0 HERE (a select, so a garbage errorEstimation of a
  * missing range never enters): the sweeps, which run 10-60 times per step, then read the weight as it is. */
 template <class SC>
@@ -494,7 +551,9 @@ KFPOS_FN uint32_t step_ml(double pos[3], double cov[6], SC &sc, const Params &pr
             m3 += w * gy * gy; m4 += w * gy * gz; m5 += w * gz * gz;
         });
         const double m[6] = {m0, m1, m2, m3, m4, m5};
-        const double idet = 1.0 / sym3_cofactors(m, cf);
+        const double det = sym3_cofactors(m, cf);
+        if (det == 0.0) return ST_UPDATE_SKIPPED; /* inv() of an exactly singular J' W J throws */
+        const double idet = 1.0 / det;
         KFPOS_UNROLL
         for (int k = 0; k < 6; ++k) c[k] = cf[k] * idet;
     }
@@ -542,12 +601,135 @@ KFPOS_FN void predict6(Cov<6, SYMM> &P, double t, double accel_noise) {
     }
 }
 
+/* ---- exact delta' pinv(P) delta for the one case without a closed form --------------------------------------
+ * With ML initialisation the 6-state filter's P is NON-symmetric (column slip, KalmanFilterTOA.cpp:102-104) and, until
+ * enough process noise has been added (one epoch; longer while dt = 0), rank-deficient: then delta' pinv(P) delta of
+ * the convergence cost (KalmanFilterTOA.cpp:290, 303) is not w' P_pp w. Those epochs take the reference's own route,
+ * an SVD pseudo-inverse with its tolerance max(m,n) sigma_max eps. Everything else keeps the closed form. */
+struct Pinv6 {
+    bool on;     /* false: P is comfortably full rank (or symmetric), use the closed form */
+    double *a;   /* pinv(P), row-major, element k at a[k * stride]: parked outside the register file (LDS on the GPU) */
+    int stride;
+};
+
+/* May the 6x6 P be rank-deficient? Cholesky of P'P without pivoting: a pivot below 1e-10 of the largest diagonal
+ * entry (singular-value ratio below 1e-5; rounding leaves up to ~1e-14 there for an exactly singular P) says
+ * "suspect". Liberal on purpose: the SVD path is always right, the closed form only needs an invertible P. */
+KFPOS_FN bool cov6_suspect(const Cov<6, false> &P) {
+    double g[6][6], gmax = 0.0;
+    KFPOS_UNROLL
+    for (int i = 0; i < 6; ++i) {
+        KFPOS_UNROLL
+        for (int j = 0; j <= i; ++j) {
+            double v = 0.0;
+            KFPOS_UNROLL
+            for (int k = 0; k < 6; ++k) v += P(k, i) * P(k, j);
+            g[i][j] = v;
+        }
+        gmax = (g[i][i] > gmax) ? g[i][i] : gmax;
+    }
+    bool suspect = false;
+    KFPOS_UNROLL
+    for (int j = 0; j < 6; ++j) {
+        double d = g[j][j];
+        KFPOS_UNROLL
+        for (int k = 0; k < j; ++k) d -= g[j][k] * g[j][k];
+        suspect = suspect || !(d > 1e-10 * gmax);
+        const double id = (d > 0.0) ? 1.0 / sqrt(d) : 0.0;
+        KFPOS_UNROLL
+        for (int i = j + 1; i < 6; ++i) {
+            double v = g[i][j];
+            KFPOS_UNROLL
+            for (int k = 0; k < j; ++k) v -= g[i][k] * g[j][k];
+            g[i][j] = v * id;
+        }
+    }
+    return suspect;
+}
+
+/* pinv(P) by one-sided (Hestenes) Jacobi: rotate column pairs of A = P until they are orthogonal, accumulating the
+ * rotations in V; then P = U S V' with s_j = |a_j|, u_j = a_j / s_j, and pinv(P) = sum over s_j > tol of
+ * v_j a_j' / s_j^2. The same sweep order, rotation formulas and tolerance as the oracle's restatement of arma::pinv. */
+KFPOS_FN void pinv6_jacobi(const Cov<6, false> &P, double *out, int stride) {
+    const double EPS = 2.220446049250313e-16;
+    double a[6][6], v[6][6];
+    KFPOS_UNROLL
+    for (int i = 0; i < 6; ++i) {
+        KFPOS_UNROLL
+        for (int j = 0; j < 6; ++j) { a[i][j] = P(i, j); v[i][j] = (i == j) ? 1.0 : 0.0; }
+    }
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        bool rotated = false;
+        KFPOS_UNROLL
+        for (int p = 0; p < 5; ++p) {
+            KFPOS_UNROLL
+            for (int q = p + 1; q < 6; ++q) {
+                double alpha = 0, beta = 0, gamma = 0;
+                KFPOS_UNROLL
+                for (int i = 0; i < 6; ++i) {
+                    alpha += a[i][p] * a[i][p];
+                    beta += a[i][q] * a[i][q];
+                    gamma += a[i][p] * a[i][q];
+                }
+                const bool rot = (gamma != 0.0) && (fabs(gamma) > EPS * sqrt(alpha * beta));
+                rotated = rotated || rot;
+                const double zeta = (beta - alpha) / (2.0 * (rot ? gamma : 1.0));
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c0 = 1.0 / sqrt(1.0 + t * t);
+                const double cs = rot ? c0 : 1.0, sn = rot ? c0 * t : 0.0; /* identity where no rotation is due */
+                KFPOS_UNROLL
+                for (int i = 0; i < 6; ++i) {
+                    const double up = a[i][p], uq = a[i][q];
+                    a[i][p] = cs * up - sn * uq;
+                    a[i][q] = sn * up + cs * uq;
+                    const double vp = v[i][p], vq = v[i][q];
+                    v[i][p] = cs * vp - sn * vq;
+                    v[i][q] = sn * vp + cs * vq;
+                }
+            }
+        }
+        if (!rotated) break;
+    }
+    double s2[6], smax2 = 0.0;
+    KFPOS_UNROLL
+    for (int j = 0; j < 6; ++j) {
+        double n2 = 0;
+        KFPOS_UNROLL
+        for (int i = 0; i < 6; ++i) n2 += a[i][j] * a[i][j];
+        s2[j] = n2;
+        smax2 = (n2 > smax2) ? n2 : smax2;
+    }
+    const double tol = 6.0 * sqrt(smax2) * EPS; /* max(m, n) * sigma_max * eps */
+    double inv[6];
+    KFPOS_UNROLL
+    for (int j = 0; j < 6; ++j) inv[j] = (sqrt(s2[j]) > tol) ? 1.0 / s2[j] : 0.0;
+    KFPOS_UNROLL
+    for (int i = 0; i < 6; ++i) {
+        KFPOS_UNROLL
+        for (int k = 0; k < 6; ++k) {
+            double acc = 0.0;
+            KFPOS_UNROLL
+            for (int j = 0; j < 6; ++j) acc += v[i][j] * inv[j] * a[k][j];
+            out[(6 * i + k) * stride] = acc;
+        }
+    }
+}
+
+/* Is |M P_pp| (bounded by sum of weights x trace) large enough for the adjugate's cancellation to matter? */
+template <class SC, class COV>
+KFPOS_FN bool illconditioned(const SC &sc, const Params &pr, const COV &P) {
+    double wsum = 0.0;
+    for_anchors<SC>(pr, [&](int a) { wsum += sc.W(a); });
+    return wsum * (fabs(P(0, 0)) + fabs(P(1, 1)) + fabs(P(2, 2))) > 1e3;
+}
+
 struct Iekf6Out {
     double p[3];      /* updated position */
     double mlast[6];  /* M = G' R^-1 G of the last gain iteration */
     double cost;
     int gain_iters, ml_iters;
     uint32_t flags;
+    bool pivot;       /* this step's 3x3 systems go through gauss3_solve (illconditioned()) */
 };
 
 /* First half of kalmanStep3DIgnoreAnchor (KalmanFilterTOA.cpp:268-282): ML position -> observation
@@ -572,9 +754,10 @@ KFPOS_FN void iekf6_weights(const double xhat_p[3], SC &sc, const Params &pr, ui
  * update. xhat_p: predicted position; P: predicted covariance; drop: ignored anchors. */
 template <bool SYMM, class SC>
 KFPOS_FN void iekf6(const double xhat_p[3], const Cov<6, SYMM> &P, SC &sc,
-                    const Params &pr, uint64_t drop, int max_steps, double tol, Iekf6Out &o) {
+                    const Params &pr, uint64_t drop, int max_steps, double tol, Iekf6Out &o, const Pinv6 &pinv) {
     double p[3] = {xhat_p[0], xhat_p[1], xhat_p[2]};
     double dp[3] = {0.0, 0.0, 0.0}; /* delta_p = xhat_p - p */
+    o.pivot = illconditioned(sc, pr, P);
     double qd = 0.0;               /* delta' pinv(P) delta */
     double cost = 1e20;
     KFPOS_UNROLL
@@ -617,6 +800,7 @@ KFPOS_FN void iekf6(const double xhat_p[3], const Cov<6, SYMM> &P, SC &sc,
         double w3[3];
         KFPOS_UNROLL
         for (int i = 0; i < 3; ++i) w3[i] = (adj[3 * i] * u[0] + adj[3 * i + 1] * u[1] + adj[3 * i + 2] * u[2]) * idet;
+        if (o.pivot) gauss_solve<3, 1>(a33, u, w3);
         qd = 0.0;
         KFPOS_UNROLL
         for (int i = 0; i < 3; ++i) {
@@ -624,6 +808,19 @@ KFPOS_FN void iekf6(const double xhat_p[3], const Cov<6, SYMM> &P, SC &sc,
             p[i] = xhat_p[i] + s;
             dp[i] = -s;
             qd += w3[i] * s;
+        }
+        if (!SYMM && pinv.on) { /* rank-deficient non-symmetric P: delta' pinv(P) delta as the reference forms it */
+            double dl[6];
+            KFPOS_UNROLL
+            for (int i = 0; i < 6; ++i) dl[i] = -(P(i, 0) * w3[0] + P(i, 1) * w3[1] + P(i, 2) * w3[2]);
+            qd = 0.0;
+            KFPOS_UNROLL
+            for (int i = 0; i < 6; ++i) {
+                double r = 0.0;
+                KFPOS_UNROLL
+                for (int j = 0; j < 6; ++j) r += pinv.a[(6 * i + j) * pinv.stride] * dl[j];
+                qd += dl[i] * r;
+            }
         }
         o.gain_iters++;
     }
@@ -633,7 +830,7 @@ KFPOS_FN void iekf6(const double xhat_p[3], const Cov<6, SYMM> &P, SC &sc,
 
 /* P <- (I - K H) P = P - P[:,0:3] N P[0:3,:], N = (I + M Ppp)^-1 M (KalmanFilterTOA.cpp:326) */
 template <bool SYMM>
-KFPOS_FN void cov_update6(Cov<6, SYMM> &P, const double m[6]) {
+KFPOS_FN void cov_update6(Cov<6, SYMM> &P, const double m[6], bool pivot) {
     const double mm[3][3] = {{m[0], m[1], m[2]}, {m[1], m[3], m[4]}, {m[2], m[4], m[5]}};
     double a33[9], adj[9], nn[3][3];
     KFPOS_UNROLL
@@ -649,6 +846,7 @@ KFPOS_FN void cov_update6(Cov<6, SYMM> &P, const double m[6]) {
         for (int j = 0; j < 3; ++j)
             nn[i][j] = (adj[3 * i] * mm[0][j] + adj[3 * i + 1] * mm[1][j] + adj[3 * i + 2] * mm[2][j]) * idet;
     }
+    if (pivot) gauss_solve<3, 3>(a33, &mm[0][0], &nn[0][0]);
     /* V = N P[0:3,:] (3x6), then P(i,j) -= sum_k P(i,k) V(k,j) using the old P(:,0:3) column block */
     double v[3][6], c0[6][3];
     KFPOS_UNROLL
@@ -671,8 +869,11 @@ KFPOS_FN void cov_update6(Cov<6, SYMM> &P, const double m[6]) {
 
 /* KalmanFilterTOA::estimatePositionKF (KalmanFilterTOA.cpp:70-156) for one tag and one epoch.
  * sc holds the epoch (r in metres, e). Returns the status word. */
+/* park: 36 doubles (element k at park[k * park_stride]) for the pseudo-inverse of the non-symmetric layout; unused
+ * (may be null) with SYMM = true. */
 template <bool SYMM, class SC>
-KFPOS_FN uint32_t step_toa6(Tag6<SYMM> &tg, SC &sc, const Params &pr, double dt) {
+KFPOS_FN uint32_t step_toa6(Tag6<SYMM> &tg, SC &sc, const Params &pr, double dt, double *park = nullptr,
+                            int park_stride = 0) {
     int n_valid = count_used(sc, pr, 0);
     if (!pr.use_init_pos && (isnan(tg.pos[0]) || isnan(tg.pos[1]) || isnan(tg.pos[2]))) {
         /* ML initialisation, KalmanFilterTOA.cpp:90-108 (only the COV_FULL layout gets here) */
@@ -681,7 +882,7 @@ KFPOS_FN uint32_t step_toa6(Tag6<SYMM> &tg, SC &sc, const Params &pr, double dt)
         set_weights_ml(sc, pr, 0ull);
         const int it = ml_estimate(p, sc, pr, 0, n_valid, sse);
         if (ml_covariance_throws(sc, pr, 0, n_valid, sse)) return ST_UPDATE_SKIPPED; /* reference: abort */
-        ml_covariance(p, sc, pr, sse, c);
+        if (!ml_covariance(p, sc, pr, sse, c)) return ST_UPDATE_SKIPPED;
         tg.pos[0] = p[0]; tg.pos[1] = p[1]; tg.pos[2] = p[2];
         const double cm[3][3] = {{c[0], c[1], c[2]}, {c[1], c[3], c[4]}, {c[2], c[4], c[5]}};
         KFPOS_UNROLL
@@ -710,6 +911,7 @@ KFPOS_FN uint32_t step_toa6(Tag6<SYMM> &tg, SC &sc, const Params &pr, double dt)
      * the wavefront (anchor coordinates stay scalar loads) and there is ONE call site of the solver,
      * so the kernel carries a single inlined copy of it. */
     Iekf6Out o = {};
+    Pinv6 pinv{false, park, park_stride};
     int ignored = -1;
     uint64_t chosen = drop;
     const int A = SC::NA > 0 ? SC::NA : pr.n_anchors;
@@ -736,10 +938,16 @@ KFPOS_FN uint32_t step_toa6(Tag6<SYMM> &tg, SC &sc, const Params &pr, double dt)
         if (!predicted) { /* after the first ML solve: the covariance loads have landed by now */
             predict6(tg.P, dt, pr.accel_noise);
             predicted = true;
+            if constexpr (!SYMM) {
+                if (cov6_suspect(tg.P)) {
+                    pinv.on = true;
+                    pinv6_jacobi(tg.P, pinv.a, pinv.stride);
+                }
+            }
         }
         thrown = thrown || (o.flags & ST_UPDATE_SKIPPED);
         if (thrown) continue; /* the exception leaves kalmanStep3D*: nothing after it runs */
-        iekf6(xhat_p, tg.P, sc, pr, mask, 10, 1e-3, o);
+        iekf6(xhat_p, tg.P, sc, pr, mask, 10, 1e-3, o, pinv);
         if (last) break;
         if (v < 0) {
             cost_all = o.cost;
@@ -757,7 +965,7 @@ KFPOS_FN uint32_t step_toa6(Tag6<SYMM> &tg, SC &sc, const Params &pr, double dt)
         }
     }
     if (thrown) return ST_UPDATE_SKIPPED; /* predicted covariance kept, position untouched (:151-153) */
-    cov_update6(tg.P, o.mlast);
+    cov_update6(tg.P, o.mlast, o.pivot);
     tg.pos[0] = o.p[0]; tg.pos[1] = o.p[1]; tg.pos[2] = o.p[2];
     return pack_status(o.flags, o.gain_iters, o.ml_iters, ignored);
 }
@@ -930,6 +1138,7 @@ KFPOS_FN void iekf9(const double xhat[9], const Cov<9, true> &P, SC &sc, const P
     double de[6] = {0, 0, 0, 0, 0, 0}; /* delta on the updated components (position, acceleration) */
     double wl[6] = {0, 0, 0, 0, 0, 0};
     double qd = 0.0, cost = 1e20;
+    const bool pivot = has_ranging && illconditioned(sc, pr, P);
     KFPOS_UNROLL
     for (int k = 0; k < 6; ++k) o.mrlast[k] = 0.0;
     o.dlast[0] = o.dlast[1] = o.dlast[2] = 0.0;
@@ -996,30 +1205,55 @@ KFPOS_FN void iekf9(const double xhat[9], const Cov<9, true> &P, SC &sc, const P
                 a22[i][j] = (i == j ? 1.0 : 0.0) + ma[i][0] * P(6, 6 + j) + ma[i][1] * P(7, 6 + j) + ma[i][2] * P(8, 6 + j);
             }
         }
-        double adj[9];
-        const double id1 = kf_rcp(gen3_adjugate(a11, adj));
-        double xx[3][3], y1[3]; /* X = A11^-1 A12, y1 = A11^-1 u_r */
-        KFPOS_UNROLL
-        for (int i = 0; i < 3; ++i) {
-            y1[i] = (adj[3 * i] * u[0] + adj[3 * i + 1] * u[1] + adj[3 * i + 2] * u[2]) * id1;
+        if (!pivot) {
+            double adj[9];
+            const double id1 = kf_rcp(gen3_adjugate(a11, adj));
+            double xx[3][3], y1[3]; /* X = A11^-1 A12, y1 = A11^-1 u_r */
             KFPOS_UNROLL
-            for (int j = 0; j < 3; ++j)
-                xx[i][j] = (adj[3 * i] * a12[0][j] + adj[3 * i + 1] * a12[1][j] + adj[3 * i + 2] * a12[2][j]) * id1;
-        }
-        double sc9[9], rhs[3]; /* Schur complement A22 - A21 X, rhs u_a - A21 y1 */
-        KFPOS_UNROLL
-        for (int i = 0; i < 3; ++i) {
-            rhs[i] = ua[i] - (a21[i][0] * y1[0] + a21[i][1] * y1[1] + a21[i][2] * y1[2]);
+            for (int i = 0; i < 3; ++i) {
+                y1[i] = (adj[3 * i] * u[0] + adj[3 * i + 1] * u[1] + adj[3 * i + 2] * u[2]) * id1;
+                KFPOS_UNROLL
+                for (int j = 0; j < 3; ++j)
+                    xx[i][j] = (adj[3 * i] * a12[0][j] + adj[3 * i + 1] * a12[1][j] + adj[3 * i + 2] * a12[2][j]) * id1;
+            }
+            double sc9[9], rhs[3]; /* Schur complement A22 - A21 X, rhs u_a - A21 y1 */
             KFPOS_UNROLL
-            for (int j = 0; j < 3; ++j)
-                sc9[3 * i + j] = a22[i][j] - (a21[i][0] * xx[0][j] + a21[i][1] * xx[1][j] + a21[i][2] * xx[2][j]);
+            for (int i = 0; i < 3; ++i) {
+                rhs[i] = ua[i] - (a21[i][0] * y1[0] + a21[i][1] * y1[1] + a21[i][2] * y1[2]);
+                KFPOS_UNROLL
+                for (int j = 0; j < 3; ++j)
+                    sc9[3 * i + j] = a22[i][j] - (a21[i][0] * xx[0][j] + a21[i][1] * xx[1][j] + a21[i][2] * xx[2][j]);
+            }
+            const double id2 = kf_rcp(gen3_adjugate(sc9, adj));
+            KFPOS_UNROLL
+            for (int i = 0; i < 3; ++i)
+                wl[3 + i] = (adj[3 * i] * rhs[0] + adj[3 * i + 1] * rhs[1] + adj[3 * i + 2] * rhs[2]) * id2;
+            KFPOS_UNROLL
+            for (int i = 0; i < 3; ++i) wl[i] = y1[i] - (xx[i][0] * wl[3] + xx[i][1] * wl[4] + xx[i][2] * wl[5]);
+        } else { /* ill-conditioned step: the same block elimination with pivoted 3x3 solves instead of adjugates */
+            double b4[12], x4[12]; /* [A12 | u_r] -> [X | y1] = A11^-1 [A12 | u_r] */
+            KFPOS_UNROLL
+            for (int i = 0; i < 3; ++i) {
+                KFPOS_UNROLL
+                for (int j = 0; j < 3; ++j) b4[4 * i + j] = a12[i][j];
+                b4[4 * i + 3] = u[i];
+            }
+            gauss_solve<3, 4>(a11, b4, x4);
+            double s9[9], r3[3], wa[3];
+            KFPOS_UNROLL
+            for (int i = 0; i < 3; ++i) {
+                r3[i] = ua[i] - (a21[i][0] * x4[3] + a21[i][1] * x4[7] + a21[i][2] * x4[11]);
+                KFPOS_UNROLL
+                for (int j = 0; j < 3; ++j)
+                    s9[3 * i + j] = a22[i][j] - (a21[i][0] * x4[j] + a21[i][1] * x4[4 + j] + a21[i][2] * x4[8 + j]);
+            }
+            gauss_solve<3, 1>(s9, r3, wa);
+            KFPOS_UNROLL
+            for (int i = 0; i < 3; ++i) {
+                wl[3 + i] = wa[i];
+                wl[i] = x4[4 * i + 3] - (x4[4 * i] * wa[0] + x4[4 * i + 1] * wa[1] + x4[4 * i + 2] * wa[2]);
+            }
         }
-        const double id2 = kf_rcp(gen3_adjugate(sc9, adj));
-        KFPOS_UNROLL
-        for (int i = 0; i < 3; ++i)
-            wl[3 + i] = (adj[3 * i] * rhs[0] + adj[3 * i + 1] * rhs[1] + adj[3 * i + 2] * rhs[2]) * id2;
-        KFPOS_UNROLL
-        for (int i = 0; i < 3; ++i) wl[i] = y1[i] - (xx[i][0] * wl[3] + xx[i][1] * wl[4] + xx[i][2] * wl[5]);
         /* x_e = xhat_e + P_ee w ; delta_e = -P_ee w ; delta' pinv(P) delta = w . P_ee w */
         qd = 0.0;
         KFPOS_UNROLL
@@ -1090,7 +1324,7 @@ KFPOS_FN uint32_t step_imu9(Tag9 &tg, SC &sc, const Params &pr, double dt,
         set_weights_ml(sc, pr, 0ull);
         const int it = ml_estimate(p, sc, pr, 0, n_valid, sse);
         if (ml_covariance_throws(sc, pr, 0, n_valid, sse)) return ST_UPDATE_SKIPPED; /* reference: abort */
-        ml_covariance(p, sc, pr, sse, c);
+        if (!ml_covariance(p, sc, pr, sse, c)) return ST_UPDATE_SKIPPED;
         tg.pos[0] = p[0]; tg.pos[1] = p[1]; tg.pos[2] = p[2];
         tg.P(0, 0) = c[0]; tg.P(0, 1) = c[1]; tg.P(1, 1) = c[3]; /* xy block only, :134-137 */
         return pack_status(ST_ML_INIT, 0, it, -1);
@@ -1280,7 +1514,7 @@ KFPOS_FN int ml2d_estimate(double p[2], double z, const SC &sc, const Params &pr
 
 /* inv(J' diag(max(e, e_ML))^-1 J) of estimatePosition2D (MLLocation.cpp:122-140), {00, 01, 11} */
 template <class SC>
-KFPOS_FN void ml2d_covariance(const double p[2], double z, const SC &sc, const Params &pr, double sse, double cov[3]) {
+KFPOS_FN bool ml2d_covariance(const double p[2], double z, const SC &sc, const Params &pr, double sse, double cov[3]) {
     double m0 = 0, m1 = 0, m3 = 0;
     for_anchors<SC>(pr, [&](int a) {
         if (!used(sc, a, 0)) return;
@@ -1290,8 +1524,10 @@ KFPOS_FN void ml2d_covariance(const double p[2], double z, const SC &sc, const P
         const double gx = dx * invd, gy = dy * invd;
         m0 += w * gx * gx; m1 += w * gx * gy; m3 += w * gy * gy;
     });
-    const double idet = 1.0 / (m0 * m3 - m1 * m1);
+    const double det = m0 * m3 - m1 * m1;
+    const double idet = 1.0 / det;
     cov[0] = m3 * idet; cov[1] = -m1 * idet; cov[2] = m0 * idet;
+    return det != 0.0; /* as ml_covariance */
 }
 
 /* One scalar row of the linearised update, processed sequentially (rows with uncorrelated noise may be
@@ -1546,7 +1782,7 @@ KFPOS_FN uint32_t step_planar8(Tag8 &tg, SC &sc, const Params &pr, double dt, ui
             double p[2] = {1.0, 1.0}, sse, c[3];
             it = ml2d_estimate(p, tg.z, sc, pr, n_valid, sse);
             if (ml_covariance_throws(sc, pr, 0, n_valid, sse, 3)) return ST_UPDATE_SKIPPED;
-            ml2d_covariance(p, tg.z, sc, pr, sse, c);
+            if (!ml2d_covariance(p, tg.z, sc, pr, sse, c)) return ST_UPDATE_SKIPPED;
             tg.xy[0] = p[0]; tg.xy[1] = p[1];
             c00 = c[0]; c01 = c[1]; c11 = c[2];
         } else {
@@ -1554,7 +1790,7 @@ KFPOS_FN uint32_t step_planar8(Tag8 &tg, SC &sc, const Params &pr, double dt, ui
             double p[3] = {1.0, 1.0, 4.0}, sse, c[6];
             it = ml_estimate(p, sc, pr, 0, n_valid, sse);
             if (ml_covariance_throws(sc, pr, 0, n_valid, sse)) return ST_UPDATE_SKIPPED;
-            ml_covariance(p, sc, pr, sse, c);
+            if (!ml_covariance(p, sc, pr, sse, c)) return ST_UPDATE_SKIPPED;
             tg.xy[0] = p[0]; tg.xy[1] = p[1];
             tg.z = p[2]; /* mUWBtagZ = mPosition.z, :257 */
             c00 = c[0]; c01 = c[1]; c11 = c[3];

@@ -219,10 +219,10 @@ __global__ __launch_bounds__(WAVE) void k_step_toa6(const KArgs a) {
             s = step_toa6<SYMM>(tg, sc, pr, dt);
         } else if constexpr (AS < 0) { /* compile-time count, epoch in LDS */
             StaticScratch<-AS> sc = stage_epoch_lds_n<MREAL, -AS>(a, lds, lane, t, e);
-            s = step_toa6<SYMM>(tg, sc, pr, dt);
+            s = step_toa6<SYMM>(tg, sc, pr, dt, lds + 3 * (size_t)(-AS) * WAVE + lane, WAVE);
         } else {
             Scratch sc = stage_epoch_lds<MREAL>(a, lds, lane, t, e);
-            s = step_toa6<SYMM>(tg, sc, pr, dt);
+            s = step_toa6<SYMM>(tg, sc, pr, dt, lds + 3 * (size_t)a.A * WAVE + lane, WAVE);
         }
         if (a.traj) { /* the pose a per-epoch caller would have read back (getPose at timeLag 0) */
 #pragma unroll
@@ -782,7 +782,7 @@ struct kfpos_handle {
 namespace {
 
 size_t lds_bytes(const kfpos_handle *h) { return (size_t)3 * h->cfg.max_anchors * WAVE * sizeof(double); }
-size_t park_bytes() { return (size_t)36 * WAVE * sizeof(double); } /* planar filter with sensor rows: CovSpill8 */
+size_t park_bytes() { return (size_t)36 * WAVE * sizeof(double); } /* 36 doubles per lane: CovSpill8 (planar), Pinv6 (6-state, full) */
 
 void fill_args(const kfpos_handle *h, KArgs &a) {
     std::memcpy(a.anchors, h->anchors, sizeof(a.anchors));
@@ -844,7 +844,13 @@ int static_anchors(const kfpos_handle *h) {
 
 template <bool SYMM, typename REAL, typename MREAL>
 step_kernel_t toa6_kernel(int as) {
-    if (as == 8) return k_step_toa6<SYMM, REAL, MREAL, 8>;
+    if constexpr (SYMM) {
+        if (as == 8) return k_step_toa6<true, REAL, MREAL, 8>;
+    } else {
+        /* non-symmetric layout (ML initialisation): its SVD path needs the registers a resident epoch would take
+         * (148-180 bytes/lane of scratch otherwise), so the 8-anchor epoch goes to LDS, loops still compile-time */
+        if (as == 8) return k_step_toa6<false, REAL, MREAL, -8>;
+    }
     if (as == -16) return k_step_toa6<SYMM, REAL, MREAL, -16>;
     return k_step_toa6<SYMM, REAL, MREAL, 0>;
 }
@@ -897,11 +903,13 @@ step_kernel_t step_kernel(const kfpos_handle *h, bool sensor_call = false) {
 
 int launch_step(kfpos_handle *h, const KArgs &a, hipStream_t s) {
     const int blocks = (h->cfg.n_tags + WAVE - 1) / WAVE;
-    const bool generic = h->force_generic || static_anchors(h) <= 0 ||
+    /* does the selected kernel stage the epoch in LDS? */
+    const bool generic = h->force_generic || static_anchors(h) <= 0 || (h->cfg.model == KFPOS_MODEL_TOA && h->full) ||
                          (h->cfg.model == KFPOS_MODEL_PLANAR && h->planar_sensors);
     const bool planar_sensor = h->cfg.model == KFPOS_MODEL_PLANAR && a.mode != 0;
     size_t lds = (a.mode == MODE_IMU_ONLY || planar_sensor || !generic) ? 0 : lds_bytes(h);
     if (h->cfg.model == KFPOS_MODEL_PLANAR && (h->planar_sensors || planar_sensor)) lds += park_bytes();
+    if (h->cfg.model == KFPOS_MODEL_TOA && h->full) lds += park_bytes(); /* Pinv6 of the non-symmetric layout */
     hipLaunchKernelGGL(step_kernel(h, planar_sensor), dim3(blocks), dim3(WAVE), lds, s, a);
     HIPCHK(hipGetLastError());
     h->stepped = true;
@@ -1083,9 +1091,10 @@ int kfpos_create(const kfpos_config *cfg, kfpos_handle **out) {
         kfpos_destroy(h);
         return KFPOS_ERR_HIP;
     }
-    if (lds_bytes(h) + (cfg->model == KFPOS_MODEL_PLANAR ? park_bytes() : 0) > 64 * 1024) {
-        hipError_t e_ = hipFuncSetAttribute((const void *)step_kernel(h),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(h));
+    const bool parks = cfg->model == KFPOS_MODEL_PLANAR || (cfg->model == KFPOS_MODEL_TOA && h->full);
+    if (lds_bytes(h) + (parks ? park_bytes() : 0) > 64 * 1024) {
+        hipError_t e_ = hipFuncSetAttribute((const void *)step_kernel(h), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)(lds_bytes(h) + (h->full ? park_bytes() : 0)));
         if (e_ == hipSuccess && cfg->model == KFPOS_MODEL_PLANAR) { /* the instantiation ranging epochs switch to */
             h->planar_sensors = true;
             e_ = hipFuncSetAttribute((const void *)step_kernel(h), hipFuncAttributeMaxDynamicSharedMemorySize,

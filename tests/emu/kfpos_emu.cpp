@@ -141,7 +141,7 @@ static uint32_t step_static(kfe_bank *b, int t, const int32_t *mm, const double 
     }
     if (b->model == 2) return step_ml(&b->ml_pos[3 * t], &b->ml_cov[6 * t], sc, b->pr, &b->ml_seed[3 * t]);
     if (b->model == 0 && !b->full) return step_toa6(b->t6s[t], sc, b->pr, lag);
-    if (b->model == 0) return step_toa6(b->t6f[t], sc, b->pr, lag);
+    if (b->model == 0) { double park[36]; return step_toa6(b->t6f[t], sc, b->pr, lag, park, 1); }
     return step_imu9(b->t9[t], sc, b->pr, lag, true, b->imu[t]);
 }
 
@@ -152,7 +152,7 @@ static uint32_t step_static_lds(kfe_bank *b, int t, const int32_t *mm, const dou
     StaticScratch<AS> sc;
     fill_scratch(b, mm, err, buf, sc);
     if (b->model == 0 && !b->full) return step_toa6(b->t6s[t], sc, b->pr, lag);
-    if (b->model == 0) return step_toa6(b->t6f[t], sc, b->pr, lag);
+    if (b->model == 0) { double park[36]; return step_toa6(b->t6f[t], sc, b->pr, lag, park, 1); }
     return step_imu9(b->t9[t], sc, b->pr, lag, true, b->imu[t]);
 }
 
@@ -184,7 +184,7 @@ void kfe_step_toa(kfe_bank *b, const int32_t *range_mm, const double *err_est, c
                                 : step_planar8<false>(b->t8[t], sc, b->pr, lag, rows, b->l8[t]);
             } else if (b->model == 2) st = step_ml(&b->ml_pos[3 * t], &b->ml_cov[6 * t], sc, b->pr, &b->ml_seed[3 * t]);
             else if (b->model == 0 && !b->full) st = step_toa6(b->t6s[t], sc, b->pr, lag);
-            else if (b->model == 0) st = step_toa6(b->t6f[t], sc, b->pr, lag);
+            else if (b->model == 0) { double park[36]; st = step_toa6(b->t6f[t], sc, b->pr, lag, park, 1); }
             else st = step_imu9(b->t9[t], sc, b->pr, lag, true, b->imu[t]);
         }
         b->flags[t] |= FL_STARTED;
@@ -323,6 +323,14 @@ void kfe_get_state(const kfe_bank *b, double *x, double *P) {
             else xt[k] = b->full ? b->t6f[t].pos[k] : b->t6s[t].pos[k];
         }
     }
+}
+
+/* unit access to the rank test and the Jacobi pseudo-inverse of the non-symmetric 6x6 path */
+int kfe_pinv6(const double *P, double *out) {
+    Cov<6, false> c;
+    for (int i = 0; i < 36; ++i) c.a[i] = P[i];
+    pinv6_jacobi(c, out, 1);
+    return cov6_suspect(c) ? 1 : 0;
 }
 
 void kfe_get_pose(const kfe_bank *b, double dt_ahead, double *pos, double *cov3x3, double *vel) {

@@ -12,7 +12,6 @@ from cases import CASES, CASE_BY_NAME, drive, rms_and_max
 from impls import EmuImpl, EmuStaticImpl, EmuStaticLdsImpl, OracleImpl
 
 # Bar from BASELINE.json: <= 1e-6 m RMS. Everything except the one documented case sits near 1e-12.
-TOL_RMS = {"toa6_A8_mlinit": 1e-6}
 TOL_DEFAULT_RMS, TOL_DEFAULT_MAX = 1e-9, 1e-8
 
 
@@ -25,21 +24,15 @@ def test_kernel_math_matches_oracle(case, impl):
     fe, pe, se = drive(case, impl, record=True)
     rms, mx, same_nan = rms_and_max(pe, po)
     assert same_nan
-    if case.name in TOL_RMS:
-        # 6-state ML initialisation: the reference copies column 1 of the ML covariance twice
-        # (KalmanFilterTOA.cpp:102-104), which leaves a rank-5 NON-symmetric P for one epoch; there
-        # delta' pinv(P) delta has no closed form and the kernel's value of the convergence cost
-        # differs, so a few tags take one IEKF iteration more or fewer ("known deviation").
-        assert rms <= TOL_RMS[case.name], (rms, mx)
-        assert (so != se).mean() < 0.01
-    else:
-        assert rms <= TOL_DEFAULT_RMS and mx <= TOL_DEFAULT_MAX, (rms, mx)
-        assert np.array_equal(so, se)  # same iteration counts, same flags, same ignored anchor
+    # also for the 6-state ML initialisation, whose column slip (KalmanFilterTOA.cpp:102-104) leaves a rank-deficient
+    # NON-symmetric P: those epochs take the SVD pseudo-inverse route for delta' pinv(P) delta (kfpos_core.h: Pinv6)
+    assert rms <= TOL_DEFAULT_RMS and mx <= TOL_DEFAULT_MAX, (rms, mx)
+    assert np.array_equal(so, se)  # same iteration counts, same flags, same ignored anchor
     xo, Po = fo.state()
     xe, Pe = fe.state()
     ok = np.isfinite(xo[:, 0])
     scale = np.abs(Po[ok]).max()
-    assert np.abs(Po[ok] - Pe[ok]).max() <= (1e-4 if case.name in TOL_RMS else 1e-9) * scale
+    assert np.abs(Po[ok] - Pe[ok]).max() <= 1e-9 * scale
     if case.model == 1:
         assert np.abs(xo[ok, 3:6] - xe[ok, 3:6]).max() < 1e-8  # velocity is persisted by the 9-state filter
 
@@ -52,8 +45,8 @@ def test_get_pose_extrapolation(name):
     for dt_ahead in (0.0, 0.05, 0.37):
         po, co, vo, _ = fo.pose(dt_ahead)
         pe, ce, ve = fe.pose(dt_ahead)
-        assert np.allclose(pe, po, atol=1e-8 if name != "toa6_A8_mlinit" else 1e-4)
-        assert np.allclose(ce, co, rtol=1e-6, atol=1e-12 if name != "toa6_A8_mlinit" else 1e-7)
+        assert np.allclose(pe, po, atol=1e-8)
+        assert np.allclose(ce, co, rtol=1e-6, atol=1e-12)
         if case.model == 1:
             assert np.allclose(ve, vo, atol=1e-8)
 

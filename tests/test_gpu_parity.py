@@ -27,18 +27,12 @@ def test_f64_storage_matches_oracle(case):
     fg, pg, sg = drive(case, _gpu(0), record=True)
     rms, mx, same_nan = rms_and_max(pg, po)
     assert same_nan
-    if case.name == "toa6_A8_mlinit":
-        # non-symmetric rank-5 P for one epoch after the reference's ML-init column slip; see
-        # tests/test_emu_core.py and DESIGN.md "known deviation"
-        assert rms <= RMS_BAR, (rms, mx)
-        assert (so != sg).mean() < 0.01
-    else:
-        assert rms <= 1e-9 and mx <= 1e-8, (rms, mx)
-        assert np.array_equal(so, sg)  # iteration counts, flags and ignored anchors identical
+    assert rms <= 1e-9 and mx <= 1e-8, (rms, mx)
+    assert np.array_equal(so, sg)  # iteration counts, flags and ignored anchors identical
     xo, Po = fo.state()
     xg, Pg = fg.state()
     ok = np.isfinite(xo[:, 0])
-    assert np.abs(Po[ok] - Pg[ok]).max() <= (1e-4 if case.name == "toa6_A8_mlinit" else 1e-9) * np.abs(Po[ok]).max()
+    assert np.abs(Po[ok] - Pg[ok]).max() <= 1e-9 * np.abs(Po[ok]).max()
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c.name for c in CASES])
@@ -48,11 +42,8 @@ def test_mixed_storage_matches_oracle(case):
     fg, pg, sg = drive(case, _gpu(2), real=np.float32, record=True)
     rms, mx, same_nan = rms_and_max(pg, po)
     assert same_nan
-    if case.name == "toa6_A8_mlinit":
-        assert rms <= RMS_BAR, (rms, mx)
-    else:
-        assert rms <= 1e-9 and mx <= 1e-8, (rms, mx)
-        assert np.array_equal(so, sg)
+    assert rms <= 1e-9 and mx <= 1e-8, (rms, mx)
+    assert np.array_equal(so, sg)
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c.name for c in CASES])
@@ -104,9 +95,8 @@ def test_gpu_reproduces_golden_fixture(name):
     c = CASE_BY_NAME[name]
     f, pos, st = drive(c, _gpu(0), steps=int(g["steps"]), record=True)
     rms, mx, same_nan = rms_and_max(pos, g["positions"])
-    assert same_nan and rms <= (RMS_BAR if name == "toa6_A8_mlinit" else 1e-9), (rms, mx)
-    if name != "toa6_A8_mlinit":
-        assert np.array_equal(st, g["status"])
+    assert same_nan and rms <= 1e-9, (rms, mx)
+    assert np.array_equal(st, g["status"])
 
 
 @pytest.mark.parametrize("name", ["toa6_A8_fixed", "imu9_A8_fixed"])
