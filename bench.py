@@ -240,7 +240,7 @@ def main():
             out["per_epoch_launch"] = per_epoch
         if world == 1 and not args.no_cpu_baseline:
             threads = min(os.cpu_count() or 1, 16)
-            sample_tags, sample_steps = 16384, 60
+            sample_tags, sample_steps = 16384, 220  # ~10 s of oracle time on 16 host threads
             v, secs, rms = cpu_baseline_and_rms(w, w.anchors, sample_tags, sample_steps, threads)
             out["cpu_baseline"] = {"value": v, "unit": "tag-steps/s", "cores": threads, "kind": "port",
                                    "sample": f"first {sample_tags} tags x {sample_steps} steps of the same "
