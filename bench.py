@@ -242,9 +242,12 @@ def main():
             threads = min(os.cpu_count() or 1, 16)
             sample_tags, sample_steps = 16384, 220  # ~10 s of oracle time on 16 host threads
             v, secs, rms = cpu_baseline_and_rms(w, w.anchors, sample_tags, sample_steps, threads)
+            v1, secs1, _ = cpu_baseline_and_rms(w, w.anchors, 1024, 60, 1)  # a 1-core figure beside it
             out["cpu_baseline"] = {"value": v, "unit": "tag-steps/s", "cores": threads, "kind": "port",
                                    "sample": f"first {sample_tags} tags x {sample_steps} steps of the same "
-                                             f"workload ({secs:.1f} s of oracle time)"}
+                                             f"workload ({secs:.1f} s of oracle time)",
+                                   "one_core_value": v1,
+                                   "one_core_sample": f"first 1024 tags x 60 steps ({secs1:.1f} s)"}
             out["rms_pos_err_vs_cpu_ref_m"] = rms
         print(json.dumps(out), flush=True)
     if world > 1:
