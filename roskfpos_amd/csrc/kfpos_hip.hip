@@ -3,24 +3,30 @@
  *
  * Execution model: ONE FILTER PER LANE, 64 filters per wavefront, one wavefront per workgroup.
  *  - The whole per-tag state (position, velocity, packed covariance: 21 / 36 / 45 doubles) lives in
- *    VGPRs for the duration of a step; every array index in kfpos_core.h is a compile-time constant
- *    after unrolling. At 65 536 tags there is exactly one wavefront per SIMD (1024 waves on
- *    256 CUs x 4 SIMDs), so the 512-register file per lane is free to use.
+ *    VGPRs/AGPRs for the duration of a step -- and across the epochs of a multi-epoch launch; every array
+ *    index in kfpos_core.h is a compile-time constant after unrolling. At 65 536 tags there is exactly one
+ *    wavefront per SIMD (1024 waves on 256 CUs x 4 SIMDs), so the 512-register file per lane is free to use.
+ *    No kernel may spill to scratch (checked at build time, __graft_entry__.build()).
  *  - HBM layout is component-major ([component][tag]): lane l of a wave reads element
  *    base + tag0 + l, so every state / measurement access is one fully coalesced
  *    512-byte (f64) or 256-byte (f32 / int32) wave transaction, each byte touched once.
- *  - LDS holds the epoch's measurements per lane, [anchor][lane] (lane-consecutive 8-byte words:
- *    conflict-free ds_read_b64): range in metres (the integer-mm wire value converted once, with the
- *    reference's exact `(double) mm / 1000`, Posgenerator.cpp:484), errorEstimation, and the working
- *    weight (1/e for the ML sweeps, 1/R for the IEKF sweeps). The inner sweeps (2-4 ML + 3-8 IEKF per
- *    step) then touch only LDS + SGPRs, never HBM.
+ *  - The epoch's measurements -- range in metres (the integer-mm wire value converted once, with the
+ *    reference's exact `(double) mm / 1000`, Posgenerator.cpp:484), errorEstimation, working weight (1/e for
+ *    the ML sweeps, 1/R for the IEKF sweeps) -- live in registers for 8 anchors (RegScratch) and per lane in
+ *    LDS otherwise, [anchor][lane] (lane-consecutive 8-byte words: conflict-free ds_read_b64), with
+ *    compile-time anchor loops for 16 anchors (StaticScratch) and a run-time loop for every other count. The
+ *    inner sweeps (2-4 ML + 3-20 IEKF per step) then touch only registers / LDS + SGPRs, never HBM.
+ *  - LDS also parks two 36-double objects that do not fit next to the rest: the predicted covariance of the
+ *    planar filter's sensor-row update (CovSpill8) and the pseudo-inverse of the non-symmetric 6-state layout
+ *    (Pinv6).
  *  - Anchor coordinates are wave-uniform: they travel in the kernel-argument segment and are read
  *    with scalar loads into SGPRs.
  *  - No MFMA: the largest dense object is 9x9 per filter; no cross-lane traffic at all: lanes are
  *    independent filters, so there is nothing to shuffle and no barrier in any kernel.
  *
- * Reference paths replaced: KalmanFilterTOA.cpp:70-156 / KalmanFilterTOAIMU.cpp:100-195 (step kernels),
- * KalmanFilterTOA.cpp:438-473 / KalmanFilterTOAIMU.cpp:476-510 (pose kernel).
+ * Kernels: k_step_toa6 (KalmanFilterTOA.cpp:70-156), k_step_imu9 (KalmanFilterTOAIMU.cpp:100-195), k_step_planar
+ * (KalmanFilter.cpp:224-321 with all five sensor entry points), k_step_ml (MLLocation.cpp:421-486), k_get_pose (the
+ * getPose of each of them), k_rows_to_cols / k_cols_to_rows (layout turn of the host-buffer API).
  */
 #include <hip/hip_runtime.h>
 
