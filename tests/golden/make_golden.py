@@ -31,3 +31,17 @@ if __name__ == "__main__":
         np.savez_compressed(os.path.join(HERE, c.name + ".npz"), steps=STEPS, positions=pos, status=st,
                             x_final=x, P_final=P, input_checksum=checksum)
         print(c.name, pos.shape, "finite:", bool(np.isfinite(pos[-1]).all()))
+    # 8-state planar filter: per-epoch state after every ranging epoch of the shared interleaved trace (tests/planar.py)
+    from planar import CFG, PlanarOracle, run_trace
+    from roskfpos_amd.synth import Workload
+    for name, sensors, fixed, fixed_height in [("planar_ranging_fixed", (), True, 1),
+                                               ("planar_ranging_mlinit3d", (), False, 0),
+                                               ("planar_all_sensors", ("imu", "px4", "mag", "compass"), True, 1)]:
+        w = Workload(24, 8)
+        orc = PlanarOracle(w, dict(CFG, use_fixed_height=fixed_height), w.init_positions() if fixed else None)
+        xs = []
+        st = run_trace([orc], w, STEPS, sensors, collect=lambda s, impls: xs.append(impls[0].get_state()[0].copy()))[0]
+        x, P = orc.get_state()
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), steps=STEPS, states=np.stack(xs),
+                            status=np.stack([a for a in st]), x_final=x, P_final=P, height=orc.get_height())
+        print(name, np.stack(xs).shape, "calls:", len(st))

@@ -142,3 +142,14 @@ def test_fused_trace_equals_per_epoch_launches():
     last = traj[-1].cpu().numpy().T
     np.testing.assert_array_equal(last[:, :2], xs[:, :2])
     np.testing.assert_array_equal(last[:, 2], seq.get_height())
+
+
+@pytest.mark.parametrize("name", ["planar_all_sensors", "planar_ranging_fixed", "planar_ranging_mlinit3d"])
+def test_gpu_reproduces_planar_golden(name):
+    """Against the committed fixture: no oracle library involved on the GPU box."""
+    from test_planar_oracle import replay_golden
+    g, xs, st, impl = replay_golden(name, lambda w, cfg, init: PlanarGpu(w, cfg, init))
+    np.testing.assert_array_equal(st, g["status"])
+    np.testing.assert_allclose(xs, g["states"], rtol=0, atol=1e-9, equal_nan=True)
+    np.testing.assert_allclose(impl.get_state()[1], g["P_final"], rtol=1e-6, atol=1e-12)
+    np.testing.assert_allclose(impl.get_height(), g["height"], atol=1e-12)

@@ -114,3 +114,38 @@ def test_get_pose_planar_block():
         np.testing.assert_allclose(vel[t], [pr[2], pr[3], 0.0], atol=1e-12)
         np.testing.assert_allclose(cov[t][:2, :2], Pp[:2, :2], atol=1e-14)
         assert cov[t][2, 2] == 0.01
+
+
+GOLDEN = {"planar_ranging_fixed": ((), True, 1), "planar_ranging_mlinit3d": ((), False, 0),
+          "planar_all_sensors": (("imu", "px4", "mag", "compass"), True, 1)}
+
+
+def replay_golden(name, make):
+    """Replay the trace behind tests/golden/<name>.npz through make(w, cfg, init) -> impl; returns (fixture, states, statuses, impl)."""
+    import os
+    from planar import run_trace
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+    sensors, fixed, fixed_height = GOLDEN[name]
+    w = Workload(24, 8)
+    impl = make(w, dict(CFG, use_fixed_height=fixed_height), w.init_positions() if fixed else None)
+    xs = []
+    st = run_trace([impl], w, int(g["steps"]), sensors, collect=lambda s, impls: xs.append(impls[0].get_state()[0].copy()))[0]
+    return g, np.stack(xs), np.stack(st), impl
+
+
+@pytest.mark.parametrize("name", sorted(GOLDEN))
+def test_oracle_reproduces_planar_golden(name):
+    from planar import PlanarOracle
+    g, xs, st, impl = replay_golden(name, PlanarOracle)
+    np.testing.assert_array_equal(st, g["status"])
+    np.testing.assert_allclose(xs, g["states"], rtol=0, atol=1e-12, equal_nan=True)
+    np.testing.assert_allclose(impl.get_state()[1], g["P_final"], rtol=1e-10, atol=1e-15)
+
+
+@pytest.mark.parametrize("name", sorted(GOLDEN))
+def test_kernel_body_reproduces_planar_golden(name):
+    from planar import PlanarEmu
+    g, xs, st, impl = replay_golden(name, lambda w, cfg, init: PlanarEmu(w, cfg, init, sensors=True))
+    np.testing.assert_array_equal(st, g["status"])
+    np.testing.assert_allclose(xs, g["states"], rtol=0, atol=1e-9, equal_nan=True)
+    np.testing.assert_allclose(impl.get_height(), g["height"], atol=1e-12)
