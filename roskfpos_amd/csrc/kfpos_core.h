@@ -48,6 +48,14 @@
 #define KFPOS_NOUNROLL
 #endif
 
+/* true when the predicate holds on every active lane of the wavefront (a wave-uniform value, so a branch on it
+ * does not diverge); the host build runs one tag at a time */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define KFPOS_WAVE_ALL(pred) (__all((pred) ? 1 : 0) != 0)
+#else
+#define KFPOS_WAVE_ALL(pred) (pred)
+#endif
+
 namespace kfpos {
 
 /* per-tag status word (include/kfpos.h repeats these as KFPOS_ST_*) */
@@ -1130,7 +1138,10 @@ KFPOS_FN void iekf9_weights(const double xhat[9], SC &sc, const Params &pr, bool
 }
 
 /* second part (:296-336): the IEKF loop, up to the covariance update */
-template <class SC>
+/* DIAG: the accelerometer covariance of every lane of the wavefront is diagonal (the usual case: sensor_msgs::Imu
+ * carries diag covariances), so Sigma^-1 and M_a = D Sigma^-1 D are diagonal: their 3x3 products collapse to
+ * scalings (about 90 of the 725 instructions of an iteration). Same results: the skipped terms are exact zeros. */
+template <bool DIAG, class SC>
 KFPOS_FN void iekf9(const double xhat[9], const Cov<9, true> &P, SC &sc, const Params &pr,
                     bool has_ranging, const Imu &imu, int max_steps, double tol, Iekf9Out &o) {
     const uint64_t drop = has_ranging ? 0ull : ~0ull;
@@ -1170,17 +1181,28 @@ KFPOS_FN void iekf9(const double xhat[9], const Cov<9, true> &P, SC &sc, const P
         double ua[3] = {0, 0, 0}, ma[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
         if (imu.has) {
             const double ya[3] = {imu.acc[0] - acc[0], imu.acc[1] - acc[1], imu.acc[2] - acc[2]};
-            const double wm[3][3] = {{imu.wi[0], imu.wi[1], imu.wi[2]},
-                                     {imu.wi[1], imu.wi[3], imu.wi[4]},
-                                     {imu.wi[2], imu.wi[4], imu.wi[5]}};
             const double va[3] = {ya[0] - acc[0] * de[3], ya[1] - acc[1] * de[4], ya[2] - acc[2] * de[5]};
-            KFPOS_UNROLL
-            for (int i = 0; i < 3; ++i) {
-                const double wy = wm[i][0] * ya[0] + wm[i][1] * ya[1] + wm[i][2] * ya[2];
-                c += ya[i] * wy;
-                ua[i] = acc[i] * (wm[i][0] * va[0] + wm[i][1] * va[1] + wm[i][2] * va[2]);
+            if constexpr (DIAG) {
+                const double wd[3] = {imu.wi[0], imu.wi[3], imu.wi[5]};
                 KFPOS_UNROLL
-                for (int j = 0; j < 3; ++j) ma[i][j] = acc[i] * acc[j] * wm[i][j];
+                for (int i = 0; i < 3; ++i) { /* same operation order as the full path: bit-identical results */
+                    const double wy = wd[i] * ya[i];
+                    c += ya[i] * wy;
+                    ua[i] = acc[i] * (wd[i] * va[i]);
+                    ma[i][i] = acc[i] * acc[i] * wd[i];
+                }
+            } else {
+                const double wm[3][3] = {{imu.wi[0], imu.wi[1], imu.wi[2]},
+                                         {imu.wi[1], imu.wi[3], imu.wi[4]},
+                                         {imu.wi[2], imu.wi[4], imu.wi[5]}};
+                KFPOS_UNROLL
+                for (int i = 0; i < 3; ++i) {
+                    const double wy = wm[i][0] * ya[0] + wm[i][1] * ya[1] + wm[i][2] * ya[2];
+                    c += ya[i] * wy;
+                    ua[i] = acc[i] * (wm[i][0] * va[0] + wm[i][1] * va[1] + wm[i][2] * va[2]);
+                    KFPOS_UNROLL
+                    for (int j = 0; j < 3; ++j) ma[i][j] = acc[i] * acc[j] * wm[i][j];
+                }
             }
         }
         if (fabs(cost - c) / cost < tol) break; /* KalmanFilterTOAIMU.cpp:316 */
@@ -1201,8 +1223,13 @@ KFPOS_FN void iekf9(const double xhat[9], const Cov<9, true> &P, SC &sc, const P
             for (int j = 0; j < 3; ++j) {
                 a11[3 * i + j] = (i == j ? 1.0 : 0.0) + mr[i][0] * P(0, j) + mr[i][1] * P(1, j) + mr[i][2] * P(2, j);
                 a12[i][j] = mr[i][0] * P(0, 6 + j) + mr[i][1] * P(1, 6 + j) + mr[i][2] * P(2, 6 + j);
-                a21[i][j] = ma[i][0] * P(6, j) + ma[i][1] * P(7, j) + ma[i][2] * P(8, j);
-                a22[i][j] = (i == j ? 1.0 : 0.0) + ma[i][0] * P(6, 6 + j) + ma[i][1] * P(7, 6 + j) + ma[i][2] * P(8, 6 + j);
+                if constexpr (DIAG) {
+                    a21[i][j] = ma[i][i] * P(6 + i, j);
+                    a22[i][j] = (i == j ? 1.0 : 0.0) + ma[i][i] * P(6 + i, 6 + j);
+                } else {
+                    a21[i][j] = ma[i][0] * P(6, j) + ma[i][1] * P(7, j) + ma[i][2] * P(8, j);
+                    a22[i][j] = (i == j ? 1.0 : 0.0) + ma[i][0] * P(6, 6 + j) + ma[i][1] * P(7, 6 + j) + ma[i][2] * P(8, 6 + j);
+                }
             }
         }
         if (!pivot) {
@@ -1343,7 +1370,10 @@ KFPOS_FN uint32_t step_imu9(Tag9 &tg, SC &sc, const Params &pr, double dt,
     /* The 9-state filter has no try/catch: the reference node aborts here. This core keeps the predicted
      * covariance and reports the tag instead. */
     if (o.flags & ST_UPDATE_SKIPPED) return ST_UPDATE_SKIPPED;
-    iekf9(xhat, tg.P, sc, pr, has_ranging, imu, 20, 1e-4, o);
+    /* exact zeros only: the whitener of a diagonal covariance produces them */
+    const bool diag = !imu.has || (imu.wi[1] == 0.0 && imu.wi[2] == 0.0 && imu.wi[4] == 0.0);
+    if (KFPOS_WAVE_ALL(diag)) iekf9<true>(xhat, tg.P, sc, pr, has_ranging, imu, 20, 1e-4, o);
+    else iekf9<false>(xhat, tg.P, sc, pr, has_ranging, imu, 20, 1e-4, o);
     cov_update9(tg.P, o.mrlast, o.dlast, imu);
     KFPOS_UNROLL
     for (int k = 0; k < 3; ++k) { tg.pos[k] = o.x[k]; tg.vel[k] = o.x[3 + k]; } /* :189-194 */
