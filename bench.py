@@ -208,13 +208,13 @@ def main():
                 traffic = None
         # what actually bounds the step kernel: fp64 VALU issue (committed PMC summary of this same command)
         valu = None
-        ppath = os.path.join(ROOT, "profiles", "r01g_pmc_sq_counters.json")
+        ppath = os.path.join(ROOT, "profiles", "r01h_pmc_sq_counters.json")
         if os.path.exists(ppath):
             try:
                 c = next(v for k, v in json.load(open(ppath)).items() if "k_step_imu9" in k)
                 valu = {"busy_frac": c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"],
                         "fp64_instr_per_wave_epoch": c["SQ_INSTS_VALU"] / c["SQ_WAVES"] / 25,
-                        "source": "profiles/r01g_pmc_sq_counters.json (rocprofv3 --pmc, 25 epochs per launch)"}
+                        "source": "profiles/r01h_pmc_sq_counters.json (rocprofv3 --pmc, 25 epochs per launch)"}
             except Exception:
                 valu = None
         out = {
