@@ -251,3 +251,27 @@ def test_full_size_properties_config3():
     xo, _ = orc.get_state()
     rms = np.sqrt(((xo[:, :3] - xf[idx, :3]) ** 2).sum(1).mean())
     assert rms <= RMS_BAR, rms
+
+
+def test_diagonal_covariance_fast_path_is_bit_identical():
+    """The 9-state iteration has a wave-uniform fast path for diagonal accelerometer covariances. A tag's result must
+    not depend on its wave-mates: one tag with a full covariance sends the whole wavefront down the general path, and
+    the other 63 must come out bit for bit as they do on the fast path."""
+    from roskfpos_amd import capi
+    from roskfpos_amd.synth import Workload
+    T, S = 64, 25
+    w = Workload(T, 8)
+    cov_diag = w.accel_cov()
+    cov_diag[:, 0], cov_diag[:, 4], cov_diag[:, 8] = 0.010, 0.012, 0.009  # diagonal, unequal
+    cov_mixed = cov_diag.copy()
+    cov_mixed[5] = np.array([[0.010, 0.002, -0.001], [0.002, 0.012, 0.003], [-0.001, 0.003, 0.009]]).ravel()
+    out = []
+    for cov in (cov_diag, cov_mixed):
+        b = capi.KfposBank(capi.MODEL_TOA_IMU, T, w.anchors, init_pos=w.init_positions())
+        for s in range(S):
+            b.step_toa_imu(w.ranges_mm(s), w.err_est(), w.accel(s), cov, w.dt_of(s))
+        out.append(b.get_state()[:2])
+    keep = np.arange(T) != 5
+    np.testing.assert_array_equal(out[0][0][keep], out[1][0][keep])
+    np.testing.assert_array_equal(out[0][1][keep], out[1][1][keep])
+    assert not np.array_equal(out[0][0][5], out[1][0][5])
