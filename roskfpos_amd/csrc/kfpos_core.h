@@ -1733,10 +1733,14 @@ KFPOS_FN void iekf8(const double xhat[8], double z, const PM &P, Cov<8, true> &P
             const double one[1] = {1.0};
             const double rp0 = ypx[0] + row_dot8<2, 3, 6, 7>(dprev, hp0), rp1 = ypx[1] + row_dot8<2, 3, 6, 7>(dprev, hp1),
                          rp2 = ypx[2] + dprev[7];
+            /* a row group no lane of the wavefront carries is skipped altogether (wave-uniform branch); within a
+             * wavefront that carries it, lanes without it run it as a no-op */
             const bool onp = (rows & ROW_PX4) != 0;
-            seq_row8<2, 3, 6, 7>(Pout, dl, hp0, lt.px4[3], rp0, onp);
-            seq_row8<2, 3, 6, 7>(Pout, dl, hp1, lt.px4[3], rp1, onp);
-            seq_row8<7>(Pout, dl, one, lt.px4[4], rp2, onp);
+            if (!KFPOS_WAVE_ALL(!onp)) {
+                seq_row8<2, 3, 6, 7>(Pout, dl, hp0, lt.px4[3], rp0, onp);
+                seq_row8<2, 3, 6, 7>(Pout, dl, hp1, lt.px4[3], rp1, onp);
+                seq_row8<7>(Pout, dl, one, lt.px4[4], rp2, onp);
+            }
             /* accelerometer pair (:657-686): decorrelate with the LDL' of its 2x2 noise block (taken as
              * symmetric: c01 is used for both off-diagonal entries): row1' = row1 - (c01 / c00) row0 */
             const double hi0[3] = {cs, sn, -sn * ax + cs * ay};
@@ -1746,12 +1750,14 @@ KFPOS_FN void iekf8(const double xhat[8], double z, const PM &P, Cov<8, true> &P
                          ri2 = yim[2] + dprev[7];
             const double lc = lt.imu[4] / lt.imu[3];
             const double hi1d[3] = {hi1[0] - lc * hi0[0], hi1[1] - lc * hi0[1], hi1[2] - lc * hi0[2]};
-            seq_row8<4, 5, 6>(Pout, dl, hi0, lt.imu[3], ri0, oni);
-            seq_row8<4, 5, 6>(Pout, dl, hi1d, lt.imu[6] - lc * lt.imu[4], ri1 - lc * ri0, oni);
-            seq_row8<7>(Pout, dl, one, lt.imu[7], ri2, oni);
+            if (!KFPOS_WAVE_ALL(!oni)) {
+                seq_row8<4, 5, 6>(Pout, dl, hi0, lt.imu[3], ri0, oni);
+                seq_row8<4, 5, 6>(Pout, dl, hi1d, lt.imu[6] - lc * lt.imu[4], ri1 - lc * ri0, oni);
+                seq_row8<7>(Pout, dl, one, lt.imu[7], ri2, oni);
+            }
             const bool onm = (rows & ROW_MAG) != 0;
             const double rm = ymag + dprev[6];
-            seq_row8<6>(Pout, dl, one, lt.mag[1], rm, onm);
+            if (!KFPOS_WAVE_ALL(!onm)) seq_row8<6>(Pout, dl, one, lt.mag[1], rm, onm);
             /* delta' pinv(P) delta = sum over row groups of (H dl)' R^-1 (r - H dl), at the final dl */
             qd = u0 * dl[0] + u1 * dl[1] - (m0 * dl[0] * dl[0] + 2.0 * m1 * dl[0] * dl[1] + m3 * dl[1] * dl[1]);
             if (onp) {

@@ -543,7 +543,7 @@ __global__ __launch_bounds__(WAVE) void k_step_planar(const KArgs a) {
     for (int k = 0; k < 36; ++k) tg.P.a[k] = ldrow<REAL>(a.P, k, T, t32);
 
     /* SENS: the predicted covariance is parked in LDS, [36][lane], behind the generic kernel's epoch scratch */
-    const CovSpill8 park{lds + ((AS == 0 && has_ranging) ? 3 * (size_t)a.A * WAVE : 0) + lane, WAVE};
+    const CovSpill8 park{lds + ((AS <= 0 && has_ranging) ? 3 * (size_t)a.A * WAVE : 0) + lane, WAVE};
     uint32_t s = 0;
     for (int e = 0; e < a.n_steps; ++e) { /* the state stays in registers from epoch to epoch */
         const double dt = epoch_dt(a, t, e);
@@ -556,6 +556,9 @@ __global__ __launch_bounds__(WAVE) void k_step_planar(const KArgs a) {
 #pragma unroll
                 for (int k = 0; k < AS; ++k) sc.r[k] = sc.e[k] = sc.w[k] = 0.0;
             }
+            s = step_planar8<SENS>(tg, sc, pr, dt, rows, lt, park);
+        } else if constexpr (AS < 0) { /* compile-time anchor loops over the LDS-resident epoch (ranging epochs only) */
+            StaticScratch<-AS> sc = stage_epoch_lds_n<MREAL, -AS>(a, lds, lane, t, e);
             s = step_planar8<SENS>(tg, sc, pr, dt, rows, lt, park);
         } else {
             Scratch sc{nullptr, nullptr, nullptr, WAVE};
@@ -878,6 +881,8 @@ template <bool SENS, typename REAL, typename MREAL>
 step_kernel_t planar_kernel(int as) {
     if constexpr (!SENS) {
         if (as == 8) return k_step_planar<false, REAL, MREAL, 8>;
+    } else {
+        if (as == 8) return k_step_planar<true, REAL, MREAL, -8>; /* epoch in LDS, anchor loops compile-time */
     }
     return k_step_planar<SENS, REAL, MREAL, 0>;
 }
