@@ -94,10 +94,12 @@ def _write_trace(path, w, S, tag):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fixed", [1, 0])
-def test_replay_algorithm_kf_matches_oracle(tmp_path, fixed):
+@pytest.mark.parametrize("fixed,A", [(1, 8), (0, 8), (1, 4), (0, 4)])
+def test_replay_algorithm_kf_matches_oracle(tmp_path, fixed, A):
+    """A = 4 with the fixed height of config_uwb.xml is BASELINE configs[0]: one tag, four anchors, the 2-D
+    fixed-height EKF, driven through the launch-file parameter surface."""
     S, tag = 40, 2
-    w = Workload(8, 8)
+    w = Workload(8, A)
     trace = str(tmp_path / "trace.txt")
     calls = _write_trace(trace, w, S, tag)
     files = {}
@@ -115,7 +117,7 @@ def test_replay_algorithm_kf_matches_oracle(tmp_path, fixed):
 
     # the same call sequence through the oracle; initAngle is only read with useStartPosition = 1
     cfg = dict(CFG, init_angle=0.3 if fixed else 0.0)
-    w1 = Workload(1, 8, tag0=tag)
+    w1 = Workload(1, A, tag0=tag)
     orc = PlanarOracle(w1, cfg, p0[None] if fixed else None)
     cw, ca = np.eye(3).reshape(1, 9) * 1e-4, w1.accel_cov()
     last, want = None, []
