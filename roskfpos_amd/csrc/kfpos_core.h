@@ -914,17 +914,16 @@ KFPOS_FN uint32_t step_toa6(Tag6<SYMM> &tg, SC &sc, const Params &pr, double dt,
      * one per left-out range, then adopts the left-out solve with the largest r_i - |p_(-i) - b_i| if
      * that is positive and lowers the cost by more than the threshold. Here one loop walks a virtual
      * index v: v = -1 solves with every range, v = 0..A-1 leaves range v out (lanes whose range v is
-     * absent sit that trip out), v = A solves the adopted set once more for its covariance (same
-     * arithmetic, hence the same result). Without the heuristic only v = A runs. v is uniform across
-     * the wavefront (anchor coordinates stay scalar loads) and there is ONE call site of the solver,
-     * so the kernel carries a single inlined copy of it. */
-    Iekf6Out o = {};
+     * absent sit that trip out); the results of the all-ranges solve and of the best leave-one-out so far
+     * are kept (a dozen registers each), so nothing is solved twice. Without the heuristic only v = A runs,
+     * once. v is uniform across the wavefront (anchor coordinates stay scalar loads) and there is ONE call
+     * site of the solver, so the kernel carries a single inlined copy of it. */
+    Iekf6Out o = {}, o_all = {}, o_best = {};
     Pinv6 pinv{false, park, park_stride};
     int ignored = -1;
-    uint64_t chosen = drop;
     const int A = SC::NA > 0 ? SC::NA : pr.n_anchors;
     const bool heuristic = n_valid > 4 && pr.ignore_worst;
-    int i = 0, best_a = -1, best_i = -1;
+    int i = 0, best_i = -1;
     double cost_all = 0.0, max_distance = 0.0, worst_cost = 0.0;
     bool thrown = false; /* one of the solves hit the reference's std::runtime_error */
     for (int v = pr.ignore_worst ? -1 : A; v <= A; ++v) {
@@ -935,13 +934,17 @@ KFPOS_FN uint32_t step_toa6(Tag6<SYMM> &tg, SC &sc, const Params &pr, double dt,
             ra = sc.Rdyn(v);
             active = !((drop >> v) & 1ull) && ra > 0.0;
         }
-        if (last && heuristic && max_distance > 0.0 && (cost_all - worst_cost) > pr.cost_threshold) {
-            chosen = drop | (1ull << best_a); /* KalmanFilterTOA.cpp:225-233 */
-            ignored = best_i;
+        if (last && heuristic) { /* adopt one of the kept results (KalmanFilterTOA.cpp:225-233) */
+            o = o_all;
+            if (max_distance > 0.0 && (cost_all - worst_cost) > pr.cost_threshold) {
+                o = o_best;
+                ignored = best_i;
+            }
+            break;
         }
         if (!active) continue;
-        const uint64_t mask = last ? chosen : (v < 0 ? drop : (drop | (1ull << v)));
-        const int n_use = last ? (ignored >= 0 ? n_valid - 1 : n_valid) : (v < 0 ? n_valid : n_valid - 1);
+        const uint64_t mask = (last || v < 0) ? drop : (drop | (1ull << v));
+        const int n_use = (last || v < 0) ? n_valid : n_valid - 1;
         iekf6_weights(xhat_p, sc, pr, mask, n_use, o);
         if (!predicted) { /* after the first ML solve: the covariance loads have landed by now */
             predict6(tg.P, dt, pr.accel_noise);
@@ -959,6 +962,7 @@ KFPOS_FN uint32_t step_toa6(Tag6<SYMM> &tg, SC &sc, const Params &pr, double dt,
         if (last) break;
         if (v < 0) {
             cost_all = o.cost;
+            o_all = o;
         } else {
             const double dx = pr.anchors[3 * v] - o.p[0], dy = pr.anchors[3 * v + 1] - o.p[1],
                          dz = pr.anchors[3 * v + 2] - o.p[2];
@@ -966,8 +970,8 @@ KFPOS_FN uint32_t step_toa6(Tag6<SYMM> &tg, SC &sc, const Params &pr, double dt,
             if (i == 0 || diff > max_distance) { /* KalmanFilterTOA.cpp:209-214 */
                 max_distance = diff;
                 worst_cost = o.cost;
-                best_a = v;
                 best_i = i;
+                o_best = o;
             }
             ++i;
         }
