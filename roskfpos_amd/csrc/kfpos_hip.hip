@@ -190,7 +190,7 @@ __device__ inline double epoch_dt(const KArgs &a, size_t t, int s) {
 }
 
 /* ------------------------------------------------------------------ 6-state step kernel */
-template <bool SYMM, typename REAL, typename MREAL, int AS>
+template <bool SYMM, typename REAL, typename MREAL, int AS, bool HEUR = true>
 __global__ __launch_bounds__(WAVE) void k_step_toa6(const KArgs a) {
     extern __shared__ double lds[];
     const int lane = threadIdx.x;
@@ -222,13 +222,13 @@ __global__ __launch_bounds__(WAVE) void k_step_toa6(const KArgs a) {
             RegScratch<AS> sc;
             unpack_epoch<MREAL, AS>(raw, sc);
             if (e + 1 < a.n_steps) fetch_epoch<MREAL, AS>(a, t, e + 1, raw); /* next epoch in flight */
-            s = step_toa6<SYMM>(tg, sc, pr, dt);
+            s = step_toa6<SYMM, HEUR>(tg, sc, pr, dt);
         } else if constexpr (AS < 0) { /* compile-time count, epoch in LDS */
             StaticScratch<-AS> sc = stage_epoch_lds_n<MREAL, -AS>(a, lds, lane, t, e);
-            s = step_toa6<SYMM>(tg, sc, pr, dt, lds + 3 * (size_t)(-AS) * WAVE + lane, WAVE);
+            s = step_toa6<SYMM, HEUR>(tg, sc, pr, dt, lds + 3 * (size_t)(-AS) * WAVE + lane, WAVE);
         } else {
             Scratch sc = stage_epoch_lds<MREAL>(a, lds, lane, t, e);
-            s = step_toa6<SYMM>(tg, sc, pr, dt, lds + 3 * (size_t)a.A * WAVE + lane, WAVE);
+            s = step_toa6<SYMM, HEUR>(tg, sc, pr, dt, lds + 3 * (size_t)a.A * WAVE + lane, WAVE);
         }
         if (a.traj) { /* the pose a per-epoch caller would have read back (getPose at timeLag 0) */
 #pragma unroll
@@ -852,16 +852,18 @@ int static_anchors(const kfpos_handle *h) {
 }
 
 template <bool SYMM, typename REAL, typename MREAL>
-step_kernel_t toa6_kernel(int as) {
+step_kernel_t toa6_kernel(int as, bool heuristics) {
+    /* banks without an outlier heuristic (BASELINE configs 2 and 4) get instantiations with no leave-one-out loop
+     * compiled in (HEUR = false): 13 % faster at 8 anchors */
     if constexpr (SYMM) {
-        if (as == 8) return k_step_toa6<true, REAL, MREAL, 8>;
+        if (as == 8) return heuristics ? k_step_toa6<true, REAL, MREAL, 8> : k_step_toa6<true, REAL, MREAL, 8, false>;
     } else {
         /* non-symmetric layout (ML initialisation): its SVD path needs the registers a resident epoch would take
          * (148-180 bytes/lane of scratch otherwise), so the 8-anchor epoch goes to LDS, loops still compile-time */
-        if (as == 8) return k_step_toa6<false, REAL, MREAL, -8>;
+        if (as == 8) return heuristics ? k_step_toa6<false, REAL, MREAL, -8> : k_step_toa6<false, REAL, MREAL, -8, false>;
     }
     if (as == -16) return k_step_toa6<SYMM, REAL, MREAL, -16>;
-    return k_step_toa6<SYMM, REAL, MREAL, 0>;
+    return heuristics ? k_step_toa6<SYMM, REAL, MREAL, 0> : k_step_toa6<SYMM, REAL, MREAL, 0, false>;
 }
 template <typename REAL, typename MREAL>
 step_kernel_t imu9_kernel(int as) {
@@ -900,13 +902,14 @@ step_kernel_t step_kernel(const kfpos_handle *h, bool sensor_call = false) {
         return st == KFPOS_STORE_F32 ? ml_kernel<float, float>(as)
              : st == KFPOS_STORE_MIXED ? ml_kernel<double, float>(as) : ml_kernel<double, double>(as);
     if (h->cfg.model == KFPOS_MODEL_TOA) {
+        const bool heur = h->cfg.ignore_worst != 0 || h->cfg.top_n != 0;
         if (h->full)
-            return st == KFPOS_STORE_F32 ? toa6_kernel<false, float, float>(as)
-                 : st == KFPOS_STORE_MIXED ? toa6_kernel<false, double, float>(as)
-                                           : toa6_kernel<false, double, double>(as);
-        return st == KFPOS_STORE_F32 ? toa6_kernel<true, float, float>(as)
-             : st == KFPOS_STORE_MIXED ? toa6_kernel<true, double, float>(as)
-                                       : toa6_kernel<true, double, double>(as);
+            return st == KFPOS_STORE_F32 ? toa6_kernel<false, float, float>(as, heur)
+                 : st == KFPOS_STORE_MIXED ? toa6_kernel<false, double, float>(as, heur)
+                                           : toa6_kernel<false, double, double>(as, heur);
+        return st == KFPOS_STORE_F32 ? toa6_kernel<true, float, float>(as, heur)
+             : st == KFPOS_STORE_MIXED ? toa6_kernel<true, double, float>(as, heur)
+                                       : toa6_kernel<true, double, double>(as, heur);
     }
     return st == KFPOS_STORE_F32 ? imu9_kernel<float, float>(as)
          : st == KFPOS_STORE_MIXED ? imu9_kernel<double, float>(as) : imu9_kernel<double, double>(as);

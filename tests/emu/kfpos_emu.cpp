@@ -17,6 +17,13 @@
 
 using namespace kfpos;
 
+/* the instantiation the library would launch: without an outlier heuristic the HEUR = false build of the step */
+template <bool SYMM, class SC>
+static uint32_t toa6_step(Tag6<SYMM> &tg, SC &sc, const Params &pr, double lag, double *park = nullptr, int stride = 0) {
+    if (pr.ignore_worst || pr.top_n) return step_toa6<SYMM, true>(tg, sc, pr, lag, park, stride);
+    return step_toa6<SYMM, false>(tg, sc, pr, lag, park, stride);
+}
+
 struct kfe_bank {
     int model, T, A, full; /* full: COV_FULL layout (6-state ML-init mode) */
     int use_static = 0;    /* run the anchor-count-specialised (register-resident epoch) code path */
@@ -140,8 +147,8 @@ static uint32_t step_static(kfe_bank *b, int t, const int32_t *mm, const double 
                           : step_planar8<false>(b->t8[t], sc, b->pr, lag, rows, b->l8[t]);
     }
     if (b->model == 2) return step_ml(&b->ml_pos[3 * t], &b->ml_cov[6 * t], sc, b->pr, &b->ml_seed[3 * t]);
-    if (b->model == 0 && !b->full) return step_toa6(b->t6s[t], sc, b->pr, lag);
-    if (b->model == 0) { double park[36]; return step_toa6(b->t6f[t], sc, b->pr, lag, park, 1); }
+    if (b->model == 0 && !b->full) return toa6_step(b->t6s[t], sc, b->pr, lag);
+    if (b->model == 0) { double park[36]; return toa6_step(b->t6f[t], sc, b->pr, lag, park, 1); }
     return step_imu9(b->t9[t], sc, b->pr, lag, true, b->imu[t]);
 }
 
@@ -151,8 +158,8 @@ static uint32_t step_static_lds(kfe_bank *b, int t, const int32_t *mm, const dou
                                 std::vector<double> &buf) {
     StaticScratch<AS> sc;
     fill_scratch(b, mm, err, buf, sc);
-    if (b->model == 0 && !b->full) return step_toa6(b->t6s[t], sc, b->pr, lag);
-    if (b->model == 0) { double park[36]; return step_toa6(b->t6f[t], sc, b->pr, lag, park, 1); }
+    if (b->model == 0 && !b->full) return toa6_step(b->t6s[t], sc, b->pr, lag);
+    if (b->model == 0) { double park[36]; return toa6_step(b->t6f[t], sc, b->pr, lag, park, 1); }
     return step_imu9(b->t9[t], sc, b->pr, lag, true, b->imu[t]);
 }
 
@@ -183,8 +190,8 @@ void kfe_step_toa(kfe_bank *b, const int32_t *range_mm, const double *err_est, c
                 st = b->sensors ? step_planar8<true>(b->t8[t], sc, b->pr, lag, rows, b->l8[t], CovSpill8{park, 1})
                                 : step_planar8<false>(b->t8[t], sc, b->pr, lag, rows, b->l8[t]);
             } else if (b->model == 2) st = step_ml(&b->ml_pos[3 * t], &b->ml_cov[6 * t], sc, b->pr, &b->ml_seed[3 * t]);
-            else if (b->model == 0 && !b->full) st = step_toa6(b->t6s[t], sc, b->pr, lag);
-            else if (b->model == 0) { double park[36]; st = step_toa6(b->t6f[t], sc, b->pr, lag, park, 1); }
+            else if (b->model == 0 && !b->full) st = toa6_step(b->t6s[t], sc, b->pr, lag);
+            else if (b->model == 0) { double park[36]; st = toa6_step(b->t6f[t], sc, b->pr, lag, park, 1); }
             else st = step_imu9(b->t9[t], sc, b->pr, lag, true, b->imu[t]);
         }
         b->flags[t] |= FL_STARTED;
