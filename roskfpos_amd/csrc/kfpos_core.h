@@ -879,14 +879,16 @@ KFPOS_FN void cov_update6(Cov<6, SYMM> &P, const double m[6], bool pivot) {
  * sc holds the epoch (r in metres, e). Returns the status word. */
 /* park: 36 doubles (element k at park[k * park_stride]) for the pseudo-inverse of the non-symmetric layout; unused
  * (may be null) with SYMM = true. */
-template <bool SYMM, bool HEUR = true, class SC>
+/* HEUR: which outlier heuristics the bank may use -- 2: any (run-time flags decide), 1: top-N only (the caller
+ * guarantees ignore_worst = 0), 0: none (ignore_worst = 0 and top_n = 0). Knowing it at compile time lets the
+ * compiler drop the leave-one-out loop and the kept results: fewer instructions and registers for the plain filter
+ * of BASELINE configs 2 and 4 and for the top-N composition of config 5. */
+template <bool SYMM, int HEUR = 2, class SC>
 KFPOS_FN uint32_t step_toa6(Tag6<SYMM> &tg, SC &sc, const Params &pr_in, double dt, double *park = nullptr,
                             int park_stride = 0) {
-    /* HEUR = false: the bank was created without either outlier heuristic (the caller guarantees ignore_worst = 0 and
-     * top_n = 0), which lets the compiler drop the leave-one-out loop and the kept results: fewer instructions and
-     * registers for the plain filter of BASELINE configs 2 and 4 */
     Params pr = pr_in;
-    if (!HEUR) { pr.ignore_worst = 0; pr.top_n = 0; }
+    if (HEUR < 2) pr.ignore_worst = 0;
+    if (HEUR < 1) pr.top_n = 0;
     int n_valid = count_used(sc, pr, 0);
     if (!pr.use_init_pos && (isnan(tg.pos[0]) || isnan(tg.pos[1]) || isnan(tg.pos[2]))) {
         /* ML initialisation, KalmanFilterTOA.cpp:90-108 (only the COV_FULL layout gets here) */

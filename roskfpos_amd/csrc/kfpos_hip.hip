@@ -190,7 +190,7 @@ __device__ inline double epoch_dt(const KArgs &a, size_t t, int s) {
 }
 
 /* ------------------------------------------------------------------ 6-state step kernel */
-template <bool SYMM, typename REAL, typename MREAL, int AS, bool HEUR = true>
+template <bool SYMM, typename REAL, typename MREAL, int AS, int HEUR = 2>
 __global__ __launch_bounds__(WAVE) void k_step_toa6(const KArgs a) {
     extern __shared__ double lds[];
     const int lane = threadIdx.x;
@@ -852,18 +852,18 @@ int static_anchors(const kfpos_handle *h) {
 }
 
 template <bool SYMM, typename REAL, typename MREAL>
-step_kernel_t toa6_kernel(int as, bool heuristics) {
-    /* banks without an outlier heuristic (BASELINE configs 2 and 4) get instantiations with no leave-one-out loop
-     * compiled in (HEUR = false): 13 % faster at 8 anchors */
+step_kernel_t toa6_kernel(int as, int heur) {
+    /* heur: 0 = the bank has no outlier heuristic (BASELINE configs 2 and 4), 1 = top-N only (config 5), 2 = leave-one-out
+     * (with or without top-N). 0 and 1 get instantiations with no leave-one-out loop compiled in: 13 % faster at 8 anchors */
     if constexpr (SYMM) {
-        if (as == 8) return heuristics ? k_step_toa6<true, REAL, MREAL, 8> : k_step_toa6<true, REAL, MREAL, 8, false>;
+        if (as == 8) return heur ? k_step_toa6<true, REAL, MREAL, 8> : k_step_toa6<true, REAL, MREAL, 8, 0>;
     } else {
         /* non-symmetric layout (ML initialisation): its SVD path needs the registers a resident epoch would take
          * (148-180 bytes/lane of scratch otherwise), so the 8-anchor epoch goes to LDS, loops still compile-time */
-        if (as == 8) return heuristics ? k_step_toa6<false, REAL, MREAL, -8> : k_step_toa6<false, REAL, MREAL, -8, false>;
+        if (as == 8) return heur ? k_step_toa6<false, REAL, MREAL, -8> : k_step_toa6<false, REAL, MREAL, -8, 0>;
     }
-    if (as == -16) return k_step_toa6<SYMM, REAL, MREAL, -16>;
-    return heuristics ? k_step_toa6<SYMM, REAL, MREAL, 0> : k_step_toa6<SYMM, REAL, MREAL, 0, false>;
+    if (as == -16) return heur == 1 ? k_step_toa6<SYMM, REAL, MREAL, -16, 1> : k_step_toa6<SYMM, REAL, MREAL, -16>;
+    return heur ? k_step_toa6<SYMM, REAL, MREAL, 0> : k_step_toa6<SYMM, REAL, MREAL, 0, 0>;
 }
 template <typename REAL, typename MREAL>
 step_kernel_t imu9_kernel(int as) {
@@ -902,7 +902,7 @@ step_kernel_t step_kernel(const kfpos_handle *h, bool sensor_call = false) {
         return st == KFPOS_STORE_F32 ? ml_kernel<float, float>(as)
              : st == KFPOS_STORE_MIXED ? ml_kernel<double, float>(as) : ml_kernel<double, double>(as);
     if (h->cfg.model == KFPOS_MODEL_TOA) {
-        const bool heur = h->cfg.ignore_worst != 0 || h->cfg.top_n != 0;
+        const int heur = h->cfg.ignore_worst != 0 ? 2 : (h->cfg.top_n != 0 ? 1 : 0);
         if (h->full)
             return st == KFPOS_STORE_F32 ? toa6_kernel<false, float, float>(as, heur)
                  : st == KFPOS_STORE_MIXED ? toa6_kernel<false, double, float>(as, heur)

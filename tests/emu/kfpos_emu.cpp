@@ -20,8 +20,9 @@ using namespace kfpos;
 /* the instantiation the library would launch: without an outlier heuristic the HEUR = false build of the step */
 template <bool SYMM, class SC>
 static uint32_t toa6_step(Tag6<SYMM> &tg, SC &sc, const Params &pr, double lag, double *park = nullptr, int stride = 0) {
-    if (pr.ignore_worst || pr.top_n) return step_toa6<SYMM, true>(tg, sc, pr, lag, park, stride);
-    return step_toa6<SYMM, false>(tg, sc, pr, lag, park, stride);
+    if (pr.ignore_worst) return step_toa6<SYMM, 2>(tg, sc, pr, lag, park, stride);
+    if (pr.top_n) return step_toa6<SYMM, 1>(tg, sc, pr, lag, park, stride);
+    return step_toa6<SYMM, 0>(tg, sc, pr, lag, park, stride);
 }
 
 struct kfe_bank {
