@@ -275,3 +275,46 @@ def test_diagonal_covariance_fast_path_is_bit_identical():
     np.testing.assert_array_equal(out[0][0][keep], out[1][0][keep])
     np.testing.assert_array_equal(out[0][1][keep], out[1][1][keep])
     assert not np.array_equal(out[0][0][5], out[1][0][5])
+
+
+@pytest.mark.parametrize("name,model,T,A,storage,top_n", [
+    ("config2", 0, 4096, 8, 0, 0),          # 4 096 tags x 8 anchors, 6-state, fp64
+    ("config4_shard", 0, 131072, 8, 0, 0),  # one GPU's share of 1 048 576 tags, 6-state
+    ("config5", 0, 262144, 16, 1, 2),       # 262 144 tags x 16 anchors, top-N 2, f32 storage
+])
+def test_full_size_properties_six_state_configs(name, model, T, A, storage, top_n):
+    """The other BASELINE configurations at their full sizes: finite state, shard equivalence (a slice run alone is
+    bit-identical), and the oracle on a strided sample of the tags."""
+    import torch
+    from roskfpos_amd import capi
+    from roskfpos_amd.synth import Workload
+    import oracle_py
+    S = 8
+    real = np.float64 if storage == 0 else np.float32
+    w = Workload(T, A)
+    r = np.stack([w.ranges_mm(s) for s in range(S)])
+    if top_n:
+        r[:, ::5, 3] += 800  # NLOS-like bias for the ranking to react to
+    dt = np.array([w.dt_of(s) for s in range(S)])
+    rt = torch.from_numpy(np.ascontiguousarray(r.transpose(0, 2, 1))).to("cuda:0")
+    et = torch.from_numpy(np.ascontiguousarray(w.err_est(real).T)).to("cuda:0")
+    full = capi.KfposBank(model, T, w.anchors, storage=storage, top_n=top_n, init_pos=w.init_positions())
+    full.run_trace_dev(S, rt, A * T, et, 0, dt, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    xf, Pf, _ = full.get_state()
+    assert np.all(np.isfinite(xf)) and np.all(np.isfinite(Pf))
+    lo, hi = T // 2, T // 2 + 1000  # not wave-aligned on purpose
+    ws = Workload(hi - lo, A, tag0=lo)
+    shard = capi.KfposBank(model, hi - lo, w.anchors, storage=storage, top_n=top_n, init_pos=ws.init_positions())
+    for s in range(S):
+        shard.step_toa(r[s][lo:hi], ws.err_est(real), dt[s])
+    xs, Ps, _ = shard.get_state()
+    assert np.array_equal(xs, xf[lo:hi]) and np.array_equal(Ps, Pf[lo:hi])
+    idx = np.arange(0, T, max(1, T // 200))
+    orc = oracle_py.OracleBank(model, len(idx), w.anchors, top_n=top_n, init_pos=w.init_positions()[idx], n_threads=8)
+    e64 = w.err_est(real).astype(np.float64)[idx]
+    for s in range(S):
+        orc.step_toa(r[s][idx], e64, dt[s])
+    xo, _ = orc.get_state()
+    rms = np.sqrt(((xo[:, :3] - xf[idx, :3]) ** 2).sum(1).mean())
+    assert rms <= RMS_BAR, rms
