@@ -1486,29 +1486,27 @@ int kfpos_get_predicted(kfpos_handle *h, const double *dt_ahead, int32_t dt_len,
     if (!h || !dt_ahead || !x || !P || (dt_len != 1 && dt_len != h->cfg.n_tags)) return KFPOS_ERR_ARG;
     stage_reset(h);
     const size_t T = h->cfg.n_tags, n = h->n;
-    double *dx = nullptr, *dP = nullptr;
-    HIPCHK(hipMalloc((void **)&dx, n * T * sizeof(double)));
-    if (hipMalloc((void **)&dP, n * n * T * sizeof(double)) != hipSuccess) {
-        (void)hipFree(dx);
-        g_err = "hipMalloc failed";
-        return KFPOS_ERR_HIP;
-    }
+    /* component-major results + their row-major turn, all from the staging area: reserve the lot first so that no
+     * region moves while another is in use */
+    const size_t bx = n * T * sizeof(double), bP = n * n * T * sizeof(double);
+    void *probe = nullptr;
+    int rc = stage_region(h, 2 * (bx + bP) + 1024, &probe);
+    if (rc) return rc;
+    stage_reset(h);
+    void *vx = nullptr, *vP = nullptr;
+    if ((rc = stage_region(h, bx, &vx)) || (rc = stage_region(h, bP, &vP))) return rc;
+    double *dx = (double *)vx, *dP = (double *)vP;
     const double *d_each = nullptr;
-    int rc = KFPOS_OK;
     if (dt_len > 1 || T == 1) {
-        if (hipMemcpy(h->d_dt, dt_ahead, sizeof(double) * T, hipMemcpyHostToDevice) != hipSuccess) rc = KFPOS_ERR_HIP;
+        HIPCHK(hipMemcpy(h->d_dt, dt_ahead, sizeof(double) * T, hipMemcpyHostToDevice));
         d_each = h->d_dt;
     }
-    if (rc == KFPOS_OK) rc = launch_pose(h, dt_ahead[0], d_each, nullptr, nullptr, nullptr, h->d_status, nullptr, dx, dP);
-    if (rc == KFPOS_OK && hipDeviceSynchronize() != hipSuccess) rc = KFPOS_ERR_HIP;
-    if (rc == KFPOS_OK) rc = stage_out(h, x, dx, (int)n);
-    if (rc == KFPOS_OK) rc = stage_out(h, P, dP, (int)(n * n));
-    if (rc == KFPOS_OK && status &&
-        hipMemcpy(status, h->d_status, sizeof(uint32_t) * T, hipMemcpyDeviceToHost) != hipSuccess)
-        rc = KFPOS_ERR_HIP;
-    (void)hipFree(dx);
-    (void)hipFree(dP);
-    return rc;
+    if ((rc = launch_pose(h, dt_ahead[0], d_each, nullptr, nullptr, nullptr, h->d_status, nullptr, dx, dP))) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    if ((rc = stage_out(h, x, dx, (int)n))) return rc;
+    if ((rc = stage_out(h, P, dP, (int)(n * n)))) return rc;
+    if (status) HIPCHK(hipMemcpy(status, h->d_status, sizeof(uint32_t) * T, hipMemcpyDeviceToHost));
+    return KFPOS_OK;
 }
 
 int kfpos_get_state(kfpos_handle *h, double *x, double *P, uint32_t *flags) {
