@@ -286,6 +286,7 @@ KFPOS_FN void chol3_psd(const double m[6], double l[6], double il[3]) {
 struct Scratch {
     static constexpr int NA = 0; /* anchor count only known at run time */
     static constexpr int CHUNK = 0;
+    static constexpr bool COOP = false;
     double *r, *e, *w;
     int stride;
     KFPOS_HD double R(int a) const { return r[a * stride]; }
@@ -311,6 +312,7 @@ template <int N>
 struct RegScratch {
     static constexpr int NA = N;
     static constexpr int CHUNK = 0; /* register arrays need compile-time indices: one fully unrolled group */
+    static constexpr bool COOP = false;
     double r[N], e[N], w[N];
     KFPOS_HD double R(int a) const { return r[a]; }
     KFPOS_HD double E(int a) const { return e[a]; }
@@ -323,6 +325,64 @@ struct RegScratch {
         return v;
     }
 };
+/* One tag per GROUP OF 8 LANES, one anchor per lane. For small batches (a few thousand tags) the machine is mostly
+ * empty and what bounds a step is the instruction chain of a single lane; here the anchor sweeps of a tag -- most of
+ * that chain -- are spread over 8 lanes and their partial sums combined with three DPP exchanges, while the small
+ * solves run redundantly (bit-identically) on all 8. Anchor "loops" run once, for the lane's own anchor (index 0). */
+struct CoopScratch {
+    static constexpr int NA = 1;
+    static constexpr int CHUNK = 0;
+    static constexpr bool COOP = true;
+    double r, e, w;    /* this lane's range (m, <= 0: absent / no such anchor), errorEstimation, working weight */
+    double bx, by, bz; /* this lane's anchor */
+    KFPOS_HD double R(int) const { return r; }
+    KFPOS_HD double E(int) const { return e; }
+    KFPOS_HD double W(int) const { return w; }
+    KFPOS_HD void setW(int, double v) { w = v; }
+    KFPOS_HD double Rdyn(int) const { return 0.0; } /* leave-one-out is not offered in this mode */
+};
+
+/* coordinates of anchor column a */
+template <class SC>
+KFPOS_FN void anchor_of(const SC &sc, const Params &pr, int a, double &bx, double &by, double &bz) {
+    if constexpr (SC::COOP) {
+        bx = sc.bx; by = sc.by; bz = sc.bz;
+    } else {
+        bx = pr.anchors[3 * a]; by = pr.anchors[3 * a + 1]; bz = pr.anchors[3 * a + 2];
+    }
+}
+
+/* Sum of v over the 8 lanes of a group, delivered to all of them with identical bits (a butterfly: every lane adds
+ * the same two partial sums at every stage). Identity for the one-tag-per-lane layouts. */
+#if defined(__HIP_DEVICE_COMPILE__)
+KFPOS_FN double dpp_exchange(double v, int ctrl_tag) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    int plo, phi;
+    if (ctrl_tag == 0) { /* quad_perm [1,0,3,2]: lane ^ 1 */
+        plo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true);
+        phi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true);
+    } else if (ctrl_tag == 1) { /* quad_perm [2,3,0,1]: lane ^ 2 */
+        plo = __builtin_amdgcn_mov_dpp(lo, 0x4E, 0xF, 0xF, true);
+        phi = __builtin_amdgcn_mov_dpp(hi, 0x4E, 0xF, 0xF, true);
+    } else { /* row_half_mirror: lane i <-> 7 - i within each group of 8 */
+        plo = __builtin_amdgcn_mov_dpp(lo, 0x141, 0xF, 0xF, true);
+        phi = __builtin_amdgcn_mov_dpp(hi, 0x141, 0xF, 0xF, true);
+    }
+    return __hiloint2double(phi, plo);
+}
+#endif
+template <class SC>
+KFPOS_FN double group_sum(const SC &, double v) {
+    if constexpr (SC::COOP) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        v += dpp_exchange(v, 0);
+        v += dpp_exchange(v, 1);
+        v += dpp_exchange(v, 2);
+#endif
+    }
+    return v;
+}
+
 /* f(a) for every anchor column; fully unrolled when the count is static */
 template <class SC, class F>
 KFPOS_FN void for_anchors(const Params &pr, F &&f) {
@@ -348,6 +408,7 @@ template <class SC>
 KFPOS_FN int count_used(const SC &sc, const Params &pr, uint64_t drop) {
     int n = 0;
     for_anchors<SC>(pr, [&](int a) { n += used(sc, a, drop) ? 1 : 0; });
+    if constexpr (SC::COOP) n = (int)group_sum(sc, (double)n);
     return n;
 }
 
@@ -366,8 +427,9 @@ KFPOS_FN void ml_sweep(const double p[3], const SC &sc, const Params &pr, uint64
          * scheduler interleave their independent rsqrt chains */
         const bool on = used(sc, a, drop);
         const double r = sc.R(a), w = sc.W(a); /* 0 for an absent / dropped range (set_weights_*) */
-        const double dx = pr.anchors[3 * a] - p[0], dy = pr.anchors[3 * a + 1] - p[1],
-                     dz = pr.anchors[3 * a + 2] - p[2];
+        double bx, by, bz;
+        anchor_of(sc, pr, a, bx, by, bz);
+        const double dx = bx - p[0], dy = by - p[1], dz = bz - p[2];
         double d, invd;
         kf_sqrt_rsqrt_sweep(dx * dx + dy * dy + dz * dz, d, invd);
         const double rd = r - d;
@@ -386,9 +448,10 @@ KFPOS_FN void ml_sweep(const double p[3], const SC &sc, const Params &pr, uint64
         h4 += c1 * dy * dz;
         h5 += c0 + c1 * dz * dz;
     });
-    cw = cw_; sse = sse_;
-    g[0] = g0; g[1] = g1; g[2] = g2;
-    hs[0] = h0; hs[1] = h1; hs[2] = h2; hs[3] = h3; hs[4] = h4; hs[5] = h5;
+    cw = group_sum(sc, cw_); sse = group_sum(sc, sse_);
+    g[0] = group_sum(sc, g0); g[1] = group_sum(sc, g1); g[2] = group_sum(sc, g2);
+    hs[0] = group_sum(sc, h0); hs[1] = group_sum(sc, h1); hs[2] = group_sum(sc, h2);
+    hs[3] = group_sum(sc, h3); hs[4] = group_sum(sc, h4); hs[5] = group_sum(sc, h5);
 }
 
 /* SSE only (estimationError at a given position) */
@@ -396,14 +459,15 @@ template <class SC>
 KFPOS_FN double ml_sse(const double p[3], const SC &sc, const Params &pr, uint64_t drop) {
     double sse = 0.0;
     for_anchors<SC>(pr, [&](int a) {
-        const double dx = pr.anchors[3 * a] - p[0], dy = pr.anchors[3 * a + 1] - p[1],
-                     dz = pr.anchors[3 * a + 2] - p[2];
+        double bx, by, bz;
+        anchor_of(sc, pr, a, bx, by, bz);
+        const double dx = bx - p[0], dy = by - p[1], dz = bz - p[2];
         double d, invd;
         kf_sqrt_rsqrt(dx * dx + dy * dy + dz * dz, d, invd);
         const double rd = d - sc.R(a);
         sse += used(sc, a, drop) ? rd * rd : 0.0;
     });
-    return sse;
+    return group_sum(sc, sse);
 }
 
 /* Gauss-Newton loop of MLLocation.cpp:164-225. p: seed in, estimate out. Requires sc.w = 1/e.
@@ -443,15 +507,17 @@ KFPOS_FN bool ml_covariance(const double p[3], const SC &sc, const Params &pr, d
     double m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0, c[6];
     for_anchors<SC>(pr, [&](int a) {
         if (!used(sc, a, 0)) return;
-        const double dx = p[0] - pr.anchors[3 * a], dy = p[1] - pr.anchors[3 * a + 1],
-                     dz = p[2] - pr.anchors[3 * a + 2];
+        double bx, by, bz;
+        anchor_of(sc, pr, a, bx, by, bz);
+        const double dx = p[0] - bx, dy = p[1] - by, dz = p[2] - bz;
         const double invd = 1.0 / sqrt(dx * dx + dy * dy + dz * dz);
         const double w = 1.0 / stdmax(sc.E(a), sse);
         const double gx = dx * invd, gy = dy * invd, gz = dz * invd;
         m0 += w * gx * gx; m1 += w * gx * gy; m2 += w * gx * gz;
         m3 += w * gy * gy; m4 += w * gy * gz; m5 += w * gz * gz;
     });
-    const double m[6] = {m0, m1, m2, m3, m4, m5};
+    const double m[6] = {group_sum(sc, m0), group_sum(sc, m1), group_sum(sc, m2),
+                         group_sum(sc, m3), group_sum(sc, m4), group_sum(sc, m5)};
     const double det = sym3_cofactors(m, c);
     const double idet = 1.0 / det;
     KFPOS_UNROLL
@@ -469,6 +535,7 @@ KFPOS_FN bool ml_covariance_throws(const SC &sc, const Params &pr, uint64_t drop
     if (n_used < min_used) return false; /* estimatePosition returned before getting there */
     bool bad = false;
     for_anchors<SC>(pr, [&](int a) { bad = bad || (used(sc, a, drop) && stdmax(sc.E(a), sse) == 0.0); });
+    if constexpr (SC::COOP) bad = group_sum(sc, bad ? 1.0 : 0.0) > 0.0;
     return bad;
 }
 
@@ -728,6 +795,7 @@ template <class SC, class COV>
 KFPOS_FN bool illconditioned(const SC &sc, const Params &pr, const COV &P) {
     double wsum = 0.0;
     for_anchors<SC>(pr, [&](int a) { wsum += sc.W(a); });
+    wsum = group_sum(sc, wsum);
     return wsum * (fabs(P(0, 0)) + fabs(P(1, 1)) + fabs(P(2, 2))) > 1e3;
 }
 
@@ -772,10 +840,11 @@ KFPOS_FN void iekf6(const double xhat_p[3], const Cov<6, SYMM> &P, SC &sc,
     for (int k = 0; k < 6; ++k) o.mlast[k] = 0.0;
     o.gain_iters = 0;
     for (int iter = 0; iter < max_steps; ++iter) {
-        double c = qd, m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0, u0 = 0, u1 = 0, u2 = 0;
+        double c = 0.0, m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0, u0 = 0, u1 = 0, u2 = 0;
         for_anchors<SC>(pr, [&](int a) {
-            const double dx = p[0] - pr.anchors[3 * a], dy = p[1] - pr.anchors[3 * a + 1],
-                         dz = p[2] - pr.anchors[3 * a + 2];
+            double bx, by, bz;
+            anchor_of(sc, pr, a, bx, by, bz);
+            const double dx = p[0] - bx, dy = p[1] - by, dz = p[2] - bz;
             double d, invd;
             kf_sqrt_rsqrt_sweep(dx * dx + dy * dy + dz * dz, d, invd);
             const double w = sc.W(a), y = sc.R(a) - d; /* weight 0 = absent / dropped range (set_weights_iekf) */
@@ -787,6 +856,13 @@ KFPOS_FN void iekf6(const double xhat_p[3], const Cov<6, SYMM> &P, SC &sc,
             m0 += wx * gx; m1 += wx * gy; m2 += wx * gz;
             m3 += wy * gy; m4 += wy * gz; m5 += wz * gz;
         });
+        if constexpr (SC::COOP) { /* one anchor per lane: combine the group's partial sums */
+            c = group_sum(sc, c);
+            m0 = group_sum(sc, m0); m1 = group_sum(sc, m1); m2 = group_sum(sc, m2);
+            m3 = group_sum(sc, m3); m4 = group_sum(sc, m4); m5 = group_sum(sc, m5);
+            u0 = group_sum(sc, u0); u1 = group_sum(sc, u1); u2 = group_sum(sc, u2);
+        }
+        c += qd;
         /* u = G' R^-1 (y - G delta) = G' R^-1 y - M delta: the delta term once per pass, not once per anchor */
         const double m[6] = {m0, m1, m2, m3, m4, m5},
                      u[3] = {u0 - (m0 * dp[0] + m1 * dp[1] + m2 * dp[2]), u1 - (m1 * dp[0] + m3 * dp[1] + m4 * dp[2]),

@@ -155,12 +155,25 @@ class EmuStaticLdsImpl(EmuImpl):
 
 
 class GpuImpl:
-    """The product path: libkfpos_hip.so through the C ABI (host-buffer entry points)."""
+    """The product path: libkfpos_hip.so through the C ABI (host-buffer entry points). coop = False keeps small plain
+    6-state banks on the one-tag-per-lane kernels (KFPOS_NO_COOP=1, read at kfpos_create); coop = True lets the library
+    pick the 8-lanes-per-tag kernel where it applies."""
 
-    def __init__(self, case, w, init, storage=0):
+    def __init__(self, case, w, init, storage=0, coop=False):
         from roskfpos_amd import capi
-        self.b = capi.KfposBank(case.model, case.T, w.anchors, storage=storage,
-                                ignore_worst=case.ignore_worst, top_n=case.top_n, init_pos=init)
+        old = os.environ.get("KFPOS_NO_COOP")
+        if not coop:
+            os.environ["KFPOS_NO_COOP"] = "1"
+        elif old is not None:
+            del os.environ["KFPOS_NO_COOP"]
+        try:
+            self.b = capi.KfposBank(case.model, case.T, w.anchors, storage=storage,
+                                    ignore_worst=case.ignore_worst, top_n=case.top_n, init_pos=init)
+        finally:
+            if old is None:
+                os.environ.pop("KFPOS_NO_COOP", None)
+            else:
+                os.environ["KFPOS_NO_COOP"] = old
 
     def step_toa(self, r, err, dt):
         return self.b.step_toa(r, err, dt)

@@ -318,3 +318,56 @@ def test_full_size_properties_six_state_configs(name, model, T, A, storage, top_
     xo, _ = orc.get_state()
     rms = np.sqrt(((xo[:, :3] - xf[idx, :3]) ** 2).sum(1).mean())
     assert rms <= RMS_BAR, rms
+
+
+COOP_CASES = ["toa6_A8_fixed", "toa6_A4_fixed", "toa6_A5_generic", "toa6_A8_zero_err"]
+
+
+@pytest.mark.parametrize("name", COOP_CASES)
+@pytest.mark.parametrize("storage", [0, 2])
+def test_cooperative_small_batch_kernel_matches_oracle(name, storage):
+    """Small plain 6-state banks run one tag per 8 lanes (k_step_toa6_coop: anchor sweeps spread over the lanes,
+    partial sums combined by DPP). Same parity bar and status words as the one-tag-per-lane kernels; not bit-identical
+    to them (another summation order)."""
+    case = CASE_BY_NAME[name]
+    real = np.float64 if storage == 0 else np.float32
+    fo, po, so = drive(case, OracleImpl, real=real, record=True)
+    fg, pg, sg = drive(case, lambda c, w, init: GpuImpl(c, w, init, storage=storage, coop=True), real=real, record=True)
+    rms, mx, same_nan = rms_and_max(pg, po)
+    assert same_nan
+    assert rms <= 1e-9 and mx <= 1e-8, (rms, mx)
+    assert np.array_equal(so, sg)
+    xo, Po = fo.state()
+    xg, Pg = fg.state()
+    ok = np.isfinite(xo[:, 0])
+    assert np.abs(Po[ok] - Pg[ok]).max() <= 1e-9 * np.abs(Po[ok]).max()
+
+
+def test_cooperative_kernel_fused_trace_and_partial_groups():
+    """T not a multiple of 8 (a partial last wavefront of groups), multi-epoch launch = per-epoch launches, dt < 0 skips."""
+    import torch
+    from roskfpos_amd import capi
+    from roskfpos_amd.synth import Workload
+    T, A, S = 1003, 8, 30
+    w = Workload(T, A)
+    seq = capi.KfposBank(capi.MODEL_TOA, T, w.anchors, init_pos=w.init_positions())
+    rep = capi.KfposBank(capi.MODEL_TOA, T, w.anchors, init_pos=w.init_positions())
+    r = np.stack([w.ranges_mm(s) for s in range(S)])
+    dt = np.array([w.dt_of(s) for s in range(S)])
+    for s in range(S):
+        seq.step_toa(r[s], w.err_est(), dt[s])
+    rt = torch.from_numpy(np.ascontiguousarray(r.transpose(0, 2, 1))).to("cuda:0")
+    et = torch.from_numpy(np.ascontiguousarray(w.err_est().T)).to("cuda:0")
+    traj = torch.zeros(S, 3, T, dtype=torch.float64, device="cuda:0")
+    rep.run_trace_dev(S, rt, A * T, et, 0, dt, trajectory=traj, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    xs, Ps, _ = seq.get_state()
+    xr, Pr, _ = rep.get_state()
+    np.testing.assert_array_equal(xr, xs)
+    np.testing.assert_array_equal(Pr, Ps)
+    np.testing.assert_array_equal(traj[-1].cpu().numpy().T, xs[:, :3])
+    d = np.full(T, 0.05)
+    d[::4] = -1.0
+    st = seq.step_toa(w.ranges_mm(S), w.err_est(), d)
+    xa, _, _ = seq.get_state()
+    assert np.all(st[::4] == 64) and np.array_equal(xa[::4], xs[::4]) and np.all(xa[1::4, :3] != xs[1::4, :3])

@@ -28,6 +28,11 @@ CONFIGS = {
     "c3_f32": (1, 65536, 8, capi.STORE_F32, 0, False, 544),
     "c5": (0, 262144, 16, capi.STORE_F32, 2, False, 344),
     "iw8": (0, 65536, 8, capi.STORE_F64, 0, True, 560),
+    # small plain 6-state banks: where the 8-lanes-per-tag kernel (k_step_toa6_coop, KFPOS_NO_COOP=1 disables) pays off
+    "t1k": (0, 1024, 8, capi.STORE_F64, 0, False, 560),
+    "t8k": (0, 8192, 8, capi.STORE_F64, 0, False, 560),
+    "t16k": (0, 16384, 8, capi.STORE_F64, 0, False, 560),
+    "t32k": (0, 32768, 8, capi.STORE_F64, 0, False, 560),
     # 8-state planar filter (KalmanFilter): ranging-only bank, and the same with IMU + compass samples latched
     # (every ranging epoch then carries 4 sensor rows; LDS-staged kernel). state 7+36 doubles r/w, epoch 96 B,
     # trajectory 24 B, flags + status 12 B
