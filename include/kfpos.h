@@ -259,7 +259,7 @@ int kfpos_run_trace_dev(kfpos_handle *h, int32_t n_steps,
                         const double *dt_steps, double *trajectory, uint32_t *status, void *stream);
 
 /* ---- diagnostics ---- */
-const char *kfpos_last_error(void);  /* thread-local text of the last KFPOS_ERR_HIP */
+const char *kfpos_last_error(void);  /* thread-local detail of the last error (HIP failures, rejected configurations, calls out of sequence) */
 const char *kfpos_strerror(int code);
 int kfpos_version(void);
 /* name / duration helpers for benchmarks: time the last n enqueued step kernels with HIP events on the

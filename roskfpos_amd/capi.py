@@ -163,8 +163,9 @@ class KfposBank:
     def _chk(self, rc):
         if rc != 0:
             msg = self.lib.kfpos_strerror(rc).decode()
-            if rc == 2:
-                msg += ": " + self.lib.kfpos_last_error().decode()
+            detail = self.lib.kfpos_last_error().decode()
+            if detail:
+                msg += ": " + detail
             raise KfposError(msg)
 
     def close(self):

@@ -1120,16 +1120,24 @@ int kfpos_version(void) { return KFPOS_VERSION; }
 int kfpos_create(const kfpos_config *cfg, kfpos_handle **out) {
     if (!cfg || !out) return KFPOS_ERR_ARG;
     *out = nullptr;
+    g_err.clear();
+    auto bad = [](const char *why) {
+        g_err = why;
+        return KFPOS_ERR_ARG;
+    };
     if (cfg->model != KFPOS_MODEL_TOA && cfg->model != KFPOS_MODEL_TOA_IMU && cfg->model != KFPOS_MODEL_ML &&
         cfg->model != KFPOS_MODEL_PLANAR)
-        return KFPOS_ERR_ARG;
+        return bad("kfpos_config.model is not one of KFPOS_MODEL_*");
     if (cfg->storage != KFPOS_STORE_F64 && cfg->storage != KFPOS_STORE_F32 && cfg->storage != KFPOS_STORE_MIXED)
-        return KFPOS_ERR_ARG;
-    if (cfg->n_tags < 1 || cfg->max_anchors < 1 || cfg->max_anchors > KFPOS_MAX_ANCHORS) return KFPOS_ERR_ARG;
-    if (cfg->top_n < 0 || (cfg->model == KFPOS_MODEL_TOA_IMU && (cfg->top_n || cfg->ignore_worst)) ||
+        return bad("kfpos_config.storage is not one of KFPOS_STORE_*");
+    if (cfg->n_tags < 1) return bad("kfpos_config.n_tags must be >= 1");
+    if (cfg->max_anchors < 1 || cfg->max_anchors > KFPOS_MAX_ANCHORS)
+        return bad("kfpos_config.max_anchors must be 1..64 (MAX_NUM_ANCS, Posgenerator.h:74)");
+    if (cfg->top_n < 0) return bad("kfpos_config.top_n must be >= 0");
+    if ((cfg->model == KFPOS_MODEL_TOA_IMU && (cfg->top_n || cfg->ignore_worst)) ||
         (cfg->model == KFPOS_MODEL_ML && cfg->ignore_worst) ||
         (cfg->model == KFPOS_MODEL_PLANAR && (cfg->top_n || cfg->ignore_worst)))
-        return KFPOS_ERR_ARG; /* both heuristics exist for the 6-state filter only */
+        return bad("ignore_worst exists for the 6-state filter only, top_n for the 6-state filter and the ML estimator");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) {
         g_err = "no HIP device";
@@ -1251,6 +1259,7 @@ int kfpos_destroy(kfpos_handle *h) {
 int kfpos_init(kfpos_handle *h) { return h ? KFPOS_OK : KFPOS_ERR_ARG; }
 
 int kfpos_set_anchors(kfpos_handle *h, const double *xyz, const int32_t *ids, int32_t n_anchors) {
+    g_err.clear();
     (void)ids;
     if (!h || !xyz || n_anchors < 1 || n_anchors > h->cfg.max_anchors) return KFPOS_ERR_ARG;
     std::memset(h->anchors, 0, sizeof(h->anchors));
@@ -1261,6 +1270,7 @@ int kfpos_set_anchors(kfpos_handle *h, const double *xyz, const int32_t *ids, in
 }
 
 int kfpos_set_init_positions(kfpos_handle *h, const double *xyz) {
+    g_err.clear();
     if (!h || !xyz) return KFPOS_ERR_ARG;
     if (!h->cfg.use_init_pos || h->stepped) return KFPOS_ERR_STATE;
     stage_reset(h);
@@ -1277,6 +1287,7 @@ int kfpos_set_init_positions(kfpos_handle *h, const double *xyz) {
 }
 
 int kfpos_set_planar(kfpos_handle *h, const kfpos_planar_config *cfg) {
+    g_err.clear();
     if (!h || !cfg) return KFPOS_ERR_ARG;
     if (h->cfg.model != KFPOS_MODEL_PLANAR) return KFPOS_ERR_MODEL;
     if (h->stepped) return KFPOS_ERR_STATE;
@@ -1296,8 +1307,12 @@ int kfpos_state_dim(const kfpos_handle *h) { return h ? h->n : 0; }
 /* ---- device-buffer API ---- */
 int kfpos_step_toa_dev(kfpos_handle *h, const int32_t *range_mm, const void *err_est, const double *dt,
                        double dt_shared, uint32_t *status, void *stream) {
+    g_err.clear();
     if (!h || !range_mm || !err_est) return KFPOS_ERR_ARG;
-    if (!h->have_anchors) return KFPOS_ERR_STATE;
+    if (!h->have_anchors) {
+        g_err = "kfpos_set_anchors has not been called (the node drops ranges until the anchors are known, Posgenerator.cpp:92-96)";
+        return KFPOS_ERR_STATE;
+    }
     KArgs a;
     fill_args(h, a);
     a.ranges = range_mm;
@@ -1311,6 +1326,7 @@ int kfpos_step_toa_dev(kfpos_handle *h, const int32_t *range_mm, const void *err
 
 int kfpos_step_imu_dev(kfpos_handle *h, const void *accel, const void *cov, const double *dt,
                        double dt_shared, uint32_t *status, void *stream) {
+    g_err.clear();
     if (!h || !accel || !cov) return KFPOS_ERR_ARG;
     if (h->cfg.model != KFPOS_MODEL_TOA_IMU) return KFPOS_OK; /* KalmanFilterTOA::newIMUMeasurement is empty */
     KArgs a;
@@ -1337,6 +1353,7 @@ static int sensor_width(int32_t kind) {
 
 int kfpos_step_sensor_dev(kfpos_handle *h, int32_t kind, const double *data, const double *dt, double dt_shared,
                           uint32_t *status, void *stream) {
+    g_err.clear();
     if (!h || !data || sensor_width(kind) == 0) return KFPOS_ERR_ARG;
     if (h->cfg.model != KFPOS_MODEL_PLANAR) { /* the empty virtuals of PositionEstimationAlgorithm.h:26-35 */
         if (status) HIPCHK(hipMemsetAsync(status, 0, sizeof(uint32_t) * h->cfg.n_tags, (hipStream_t)stream));
@@ -1357,6 +1374,7 @@ int kfpos_step_sensor_dev(kfpos_handle *h, int32_t kind, const double *data, con
 int kfpos_step_toa_imu_dev(kfpos_handle *h, const int32_t *range_mm, const void *err_est, const void *accel,
                            const void *cov, int32_t latch, const double *dt, double dt_shared,
                            uint32_t *status, void *stream) {
+    g_err.clear();
     if (!h || !range_mm || !err_est || !accel || !cov) return KFPOS_ERR_ARG;
     if (h->cfg.model != KFPOS_MODEL_TOA_IMU) return KFPOS_ERR_MODEL;
     if (!h->have_anchors) return KFPOS_ERR_STATE;
@@ -1378,6 +1396,7 @@ int kfpos_run_trace_dev(kfpos_handle *h, int32_t n_steps, const int32_t *range_m
                         const void *err_est, int64_t stride_err, const void *accel, int64_t stride_accel,
                         const void *cov, int64_t stride_cov, const double *dt_steps, double *trajectory,
                         uint32_t *status, void *stream) {
+    g_err.clear();
     if (!h || n_steps < 0 || !range_mm || !err_est || !dt_steps) return KFPOS_ERR_ARG;
     if (accel && (!cov || h->cfg.model != KFPOS_MODEL_TOA_IMU)) return KFPOS_ERR_MODEL;
     if (!h->have_anchors) return KFPOS_ERR_STATE;
@@ -1459,14 +1478,19 @@ static int launch_pose(kfpos_handle *h, double dt_ahead, const double *dt_each, 
 
 int kfpos_get_pose_dev(kfpos_handle *h, double dt_ahead, double *pos, double *cov3x3, double *vel,
                        uint32_t *status, void *stream) {
+    g_err.clear();
     return launch_pose(h, dt_ahead, nullptr, pos, cov3x3, vel, status, stream);
 }
 
 /* ---- host-buffer API ---- */
 int kfpos_step_toa(kfpos_handle *h, const int32_t *range_mm, const void *err_est, const double *dt,
                    int32_t dt_len, uint32_t *status) {
+    g_err.clear();
     if (!h || !range_mm || !err_est) return KFPOS_ERR_ARG;
-    if (!h->have_anchors) return KFPOS_ERR_STATE;
+    if (!h->have_anchors) {
+        g_err = "kfpos_set_anchors has not been called (the node drops ranges until the anchors are known, Posgenerator.cpp:92-96)";
+        return KFPOS_ERR_STATE;
+    }
     stage_reset(h);
     const double *d_dt;
     double shared;
@@ -1480,6 +1504,7 @@ int kfpos_step_toa(kfpos_handle *h, const int32_t *range_mm, const void *err_est
 
 int kfpos_step_imu(kfpos_handle *h, const void *accel, const void *cov, const double *dt, int32_t dt_len,
                    uint32_t *status) {
+    g_err.clear();
     if (!h || !accel || !cov) return KFPOS_ERR_ARG;
     if (h->cfg.model != KFPOS_MODEL_TOA_IMU) {
         if (status) std::memset(status, 0, sizeof(uint32_t) * h->cfg.n_tags);
@@ -1498,6 +1523,7 @@ int kfpos_step_imu(kfpos_handle *h, const void *accel, const void *cov, const do
 
 int kfpos_step_sensor(kfpos_handle *h, int32_t kind, const double *data, const double *dt, int32_t dt_len,
                       uint32_t *status) {
+    g_err.clear();
     const int C = sensor_width(kind);
     if (!h || !data || C == 0) return KFPOS_ERR_ARG;
     if (h->cfg.model != KFPOS_MODEL_PLANAR) {
@@ -1515,6 +1541,7 @@ int kfpos_step_sensor(kfpos_handle *h, int32_t kind, const double *data, const d
 }
 
 int kfpos_get_height(kfpos_handle *h, double *z) {
+    g_err.clear();
     if (!h || !z) return KFPOS_ERR_ARG;
     if (h->cfg.model != KFPOS_MODEL_PLANAR) return KFPOS_ERR_MODEL;
     HIPCHK(hipDeviceSynchronize());
@@ -1524,6 +1551,7 @@ int kfpos_get_height(kfpos_handle *h, double *z) {
 
 int kfpos_step_toa_imu(kfpos_handle *h, const int32_t *range_mm, const void *err_est, const void *accel,
                        const void *cov, const double *dt, int32_t dt_len, uint32_t *status) {
+    g_err.clear();
     if (!h || !range_mm || !err_est || !accel || !cov) return KFPOS_ERR_ARG;
     if (h->cfg.model != KFPOS_MODEL_TOA_IMU) return KFPOS_ERR_MODEL;
     if (!h->have_anchors) return KFPOS_ERR_STATE;
@@ -1565,17 +1593,20 @@ static int get_pose_host(kfpos_handle *h, double dt_ahead, const double *dt_each
 
 int kfpos_get_pose(kfpos_handle *h, double dt_ahead, double *pos, double *cov3x3, double *vel,
                    uint32_t *status) {
+    g_err.clear();
     return get_pose_host(h, dt_ahead, nullptr, pos, cov3x3, vel, status);
 }
 
 int kfpos_get_pose_each(kfpos_handle *h, const double *dt_ahead, double *pos, double *cov3x3, double *vel,
                         uint32_t *status) {
+    g_err.clear();
     if (!dt_ahead) return KFPOS_ERR_ARG;
     return get_pose_host(h, 0.0, dt_ahead, pos, cov3x3, vel, status);
 }
 
 int kfpos_get_predicted(kfpos_handle *h, const double *dt_ahead, int32_t dt_len, double *x, double *P,
                         uint32_t *status) {
+    g_err.clear();
     if (!h || !dt_ahead || !x || !P || (dt_len != 1 && dt_len != h->cfg.n_tags)) return KFPOS_ERR_ARG;
     stage_reset(h);
     const size_t T = h->cfg.n_tags, n = h->n;
@@ -1603,6 +1634,7 @@ int kfpos_get_predicted(kfpos_handle *h, const double *dt_ahead, int32_t dt_len,
 }
 
 int kfpos_get_state(kfpos_handle *h, double *x, double *P, uint32_t *flags) {
+    g_err.clear();
     if (!h) return KFPOS_ERR_ARG;
     HIPCHK(hipDeviceSynchronize());
     const size_t T = h->cfg.n_tags;
@@ -1648,6 +1680,7 @@ int kfpos_get_state(kfpos_handle *h, double *x, double *P, uint32_t *flags) {
 }
 
 int kfpos_set_state(kfpos_handle *h, const double *x, const double *P, const uint32_t *flags) {
+    g_err.clear();
     if (!h) return KFPOS_ERR_ARG;
     HIPCHK(hipDeviceSynchronize());
     const size_t T = h->cfg.n_tags;
@@ -1697,11 +1730,13 @@ int kfpos_set_state(kfpos_handle *h, const double *x, const double *P, const uin
 }
 
 int kfpos_latch_dim(const kfpos_handle *h) {
+    g_err.clear();
     if (!h) return 0;
     return h->cfg.model == KFPOS_MODEL_TOA_IMU ? 12 : (h->cfg.model == KFPOS_MODEL_PLANAR ? LATCH_ROWS : 0);
 }
 
 int kfpos_get_latch(kfpos_handle *h, double *latch) {
+    g_err.clear();
     if (!h) return KFPOS_ERR_ARG;
     const int L = kfpos_latch_dim(h);
     if (L == 0) return KFPOS_OK;
@@ -1727,6 +1762,7 @@ int kfpos_get_latch(kfpos_handle *h, double *latch) {
 }
 
 int kfpos_set_latch(kfpos_handle *h, const double *latch) {
+    g_err.clear();
     if (!h) return KFPOS_ERR_ARG;
     const int L = kfpos_latch_dim(h);
     if (L == 0) return KFPOS_OK;
@@ -1751,11 +1787,13 @@ int kfpos_set_latch(kfpos_handle *h, const double *latch) {
 }
 
 int kfpos_timing_begin(kfpos_handle *h, void *stream) {
+    g_err.clear();
     if (!h) return KFPOS_ERR_ARG;
     HIPCHK(hipEventRecord(h->ev0, (hipStream_t)stream));
     return KFPOS_OK;
 }
 int kfpos_timing_end(kfpos_handle *h, void *stream, float *elapsed_ms) {
+    g_err.clear();
     if (!h || !elapsed_ms) return KFPOS_ERR_ARG;
     HIPCHK(hipEventRecord(h->ev1, (hipStream_t)stream));
     HIPCHK(hipEventSynchronize(h->ev1));

@@ -141,11 +141,11 @@ def test_not_started_and_empty_epochs():
 def test_argument_errors():
     from roskfpos_amd import capi
     from roskfpos_amd.synth import anchors_xyz
-    with pytest.raises(capi.KfposError):
+    with pytest.raises(capi.KfposError, match="model"):
         capi.KfposBank(7, 4, anchors_xyz(4), init_pos=np.zeros(3))          # unknown model
-    with pytest.raises(capi.KfposError):
+    with pytest.raises(capi.KfposError, match="n_tags"):
         capi.KfposBank(capi.MODEL_TOA, 0, anchors_xyz(4), init_pos=np.zeros(3))  # no tags
-    with pytest.raises(capi.KfposError):
+    with pytest.raises(capi.KfposError, match="6-state"):
         capi.KfposBank(capi.MODEL_TOA_IMU, 4, anchors_xyz(4), top_n=1, init_pos=np.zeros(3))
     b = capi.KfposBank(capi.MODEL_TOA, 4, anchors_xyz(4), init_pos=np.zeros(3))
     with pytest.raises(capi.KfposError):
