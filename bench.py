@@ -91,8 +91,9 @@ def cpu_baseline_and_rms(w, anchors, sample_tags, sample_steps, threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50,
+                    help="untimed epochs first; the chip needs a few launches to settle its clocks under this fp64 load")
     ap.add_argument("--tags-per-gpu", type=int, default=TAGS_PER_GPU)
     ap.add_argument("--epochs-per-launch", type=int, default=25,
                     help="epochs fused into one kernel launch (state resident in registers); 1 = one launch per epoch")
