@@ -966,8 +966,9 @@ KFPOS_FN uint32_t step_toa6(Tag6<SYMM> &tg, SC &sc, const Params &pr_in, double 
     if (HEUR < 2) pr.ignore_worst = 0;
     if (HEUR < 1) pr.top_n = 0;
     int n_valid = count_used(sc, pr, 0);
-    if (!pr.use_init_pos && (isnan(tg.pos[0]) || isnan(tg.pos[1]) || isnan(tg.pos[2]))) {
-        /* ML initialisation, KalmanFilterTOA.cpp:90-108 (only the COV_FULL layout gets here) */
+    if (!SYMM && !pr.use_init_pos && (isnan(tg.pos[0]) || isnan(tg.pos[1]) || isnan(tg.pos[2]))) {
+        /* ML initialisation, KalmanFilterTOA.cpp:90-108. Only the non-symmetric layout gets here: a bank is created
+         * with it exactly when use_init_pos = 0, so the symmetric instantiations carry no initialisation code */
         if (n_valid < 4) return ST_FEW_RANGES;
         double p[3] = {1.0, 1.0, 4.0}, sse, c[6];
         set_weights_ml(sc, pr, 0ull);
