@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Long-run parity: 2 048 tags x 2 000 epochs through the C ABI against the oracle (TEST TOOL: uses oracle/), both
+filters; prints RMS / max position difference and the fraction of differing status words every 250 epochs.
+
+    python tools/soak.py
+"""
+import sys, os, numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+from roskfpos_amd import capi
+from roskfpos_amd.synth import Workload
+import oracle_py
+T, S = 2048, 2000
+for model in (0, 1):
+    w = Workload(T, 8)
+    b = capi.KfposBank(model, T, w.anchors, init_pos=w.init_positions())
+    o = oracle_py.OracleBank(model, T, w.anchors, init_pos=w.init_positions(), n_threads=16)
+    err, cov = w.err_est(), w.accel_cov()
+    worst = 0.0
+    for s in range(S):
+        r, a, dt = w.ranges_mm(s), w.accel(s), w.dt_of(s)
+        if model == 1:
+            sb = b.step_toa_imu(r, err, a, cov, dt); o.step_imu(a, cov, 0.0); so = o.step_toa(r, err, dt)
+        else:
+            sb = b.step_toa(r, err, dt); so = o.step_toa(r, err, dt)
+        if s % 250 == 249 or s == S - 1:
+            xb = b.get_state()[0]; xo = o.get_state()[0]
+            rms = float(np.sqrt(((xb[:, :3] - xo[:, :3]) ** 2).sum(1).mean()))
+            worst = max(worst, rms)
+            print(f"model {model} step {s+1}: rms {rms:.3e} max {np.abs(xb[:, :3]-xo[:, :3]).max():.3e} status-mismatch {(sb != so).mean():.4f}", flush=True)
