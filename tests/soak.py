@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Long-run parity: 2 048 tags x 2 000 epochs through the C ABI against the oracle (TEST TOOL: uses oracle/), both
+"""Long-run parity: 2 048 tags x 2 000 epochs through the C ABI against the oracle (test infrastructure: it uses oracle/, hence it lives under tests/), both
 filters; prints RMS / max position difference and the fraction of differing status words every 250 epochs.
 
-    python tools/soak.py
+    python tests/soak.py
 """
 import sys, os, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
