@@ -1,0 +1,418 @@
+/*
+ * kfpos_core_imu9.h -- part of kfpos_core.h (include that, not this): per-tag arithmetic shared by the HIP kernels and
+ * the host emulation of the tests.
+ * 9-state filter: KalmanFilterTOAIMU (KalmanFilterTOAIMU.cpp:100-195, 242-340, with the 3-token repair).
+ */
+#ifndef KFPOS_CORE_IMU9_H
+#define KFPOS_CORE_IMU9_H
+
+namespace kfpos {
+
+/* ================================================================== 9-state filter (KalmanFilterTOAIMU) */
+struct Tag9 {
+    double pos[3], vel[3];
+    Cov<9, true> P;
+};
+struct Imu {
+    bool has;      /* hasImuMeasurement */
+    double acc[3]; /* linearAcceleration */
+    double ci[6];  /* inverse Cholesky factor of the covariance, lower {00,10,20,11,21,22}: Sigma^-1 = Ci' Ci */
+    double wi[6];  /* Sigma^-1 itself, symmetric {00,01,02,11,12,22} */
+};
+
+/* Sigma (row-major 3x3, symmetric positive definite; the lower triangle is read) -> Ci with
+ * Sigma^-1 = Ci' Ci, and Sigma^-1 = Ci' Ci itself */
+KFPOS_FN void imu_whitener(const double s[9], double ci[6], double wi[6]) {
+    double c00, c11, c22, i00, i11, i22;
+    kf_sqrt_rsqrt(s[0], c00, i00);
+    const double c10 = s[3] * i00, c20 = s[6] * i00;
+    kf_sqrt_rsqrt(s[4] - c10 * c10, c11, i11);
+    const double c21 = (s[7] - c20 * c10) * i11;
+    kf_sqrt_rsqrt(s[8] - c20 * c20 - c21 * c21, c22, i22);
+    const double i10 = -c10 * i00 * i11;
+    const double i21 = -c21 * i11 * i22;
+    const double i20 = -(c20 * i00 + c21 * i10) * i22;
+    ci[0] = i00; ci[1] = i10; ci[2] = i20; ci[3] = i11; ci[4] = i21; ci[5] = i22;
+    wi[0] = i00 * i00 + i10 * i10 + i20 * i20;
+    wi[1] = i10 * i11 + i20 * i21;
+    wi[2] = i20 * i22;
+    wi[3] = i11 * i11 + i21 * i21;
+    wi[4] = i21 * i22;
+    wi[5] = i22 * i22;
+}
+
+/* KalmanFilterTOAIMU.cpp:170-180, 392-421 */
+KFPOS_FN void predict9(Cov<9, true> &P, double t, double jolt) {
+    const double c = t * t / 2;
+    /* blocks: p = 0..2, v = 3..5, a = 6..8; each block is updated from not-yet-overwritten ones */
+    KFPOS_UNROLL
+    for (int i = 0; i < 3; ++i) {
+        KFPOS_UNROLL
+        for (int j = i; j < 3; ++j) {
+            const double xpp = P(i, j) + t * P(3 + i, j) + c * P(6 + i, j);
+            const double xpv = P(i, 3 + j) + t * P(3 + i, 3 + j) + c * P(6 + i, 3 + j);
+            const double xpa = P(i, 6 + j) + t * P(3 + i, 6 + j) + c * P(6 + i, 6 + j);
+            P(i, j) = xpp + t * xpv + c * xpa;
+        }
+    }
+    KFPOS_UNROLL
+    for (int i = 0; i < 3; ++i) {
+        KFPOS_UNROLL
+        for (int j = 0; j < 3; ++j) {
+            const double xpv = P(i, 3 + j) + t * P(3 + i, 3 + j) + c * P(6 + i, 3 + j);
+            const double xpa = P(i, 6 + j) + t * P(3 + i, 6 + j) + c * P(6 + i, 6 + j);
+            P(i, 3 + j) = xpv + t * xpa;
+        }
+    }
+    KFPOS_UNROLL
+    for (int i = 0; i < 3; ++i) {
+        KFPOS_UNROLL
+        for (int j = 0; j < 3; ++j) P(i, 6 + j) = P(i, 6 + j) + t * P(3 + i, 6 + j) + c * P(6 + i, 6 + j);
+    }
+    KFPOS_UNROLL
+    for (int i = 0; i < 3; ++i) {
+        KFPOS_UNROLL
+        for (int j = i; j < 3; ++j) {
+            const double xvv = P(3 + i, 3 + j) + t * P(6 + i, 3 + j);
+            const double xva = P(3 + i, 6 + j) + t * P(6 + i, 6 + j);
+            P(3 + i, 3 + j) = xvv + t * xva;
+        }
+    }
+    KFPOS_UNROLL
+    for (int i = 0; i < 3; ++i) {
+        KFPOS_UNROLL
+        for (int j = 0; j < 3; ++j) P(3 + i, 6 + j) = P(3 + i, 6 + j) + t * P(6 + i, 6 + j);
+    }
+    const double u[3] = {(t * t * t) / 6, (t * t) / 2, t};
+    KFPOS_UNROLL
+    for (int k = 0; k < 3; ++k) {
+        KFPOS_UNROLL
+        for (int a = 0; a < 3; ++a) {
+            KFPOS_UNROLL
+            for (int b = a; b < 3; ++b) P(k + 3 * a, k + 3 * b) += jolt * u[a] * u[b];
+        }
+    }
+}
+
+/* index of the k-th updated state component: position 0..2, acceleration 6..8 */
+KFPOS_HD constexpr int e9(int k) { return k < 3 ? k : k + 3; }
+
+/* L = blockdiag(L_r, L_a): M_r = L_r L_r' (lower, psd Cholesky), M_a = D Sigma^-1 D = L_a L_a'
+ * with L_a = D Ci' (upper). lt[k][l] = L(k, l) as a dense 6x6 with structural zeros. */
+struct Factor9 {
+    double lr[6], ilr[3]; /* chol3_psd of M_r */
+    double la[6];         /* upper {00,01,02,11,12,22}: la(k,l) = a_k * ci(l,k) */
+};
+KFPOS_FN void factor9(const double mr[6], const double acc[3], const Imu &imu, Factor9 &f) {
+    chol3_psd(mr, f.lr, f.ilr);
+    if (imu.has) {
+        f.la[0] = acc[0] * imu.ci[0]; f.la[1] = acc[0] * imu.ci[1]; f.la[2] = acc[0] * imu.ci[2];
+        f.la[3] = acc[1] * imu.ci[3]; f.la[4] = acc[1] * imu.ci[4];
+        f.la[5] = acc[2] * imu.ci[5];
+    } else {
+        KFPOS_UNROLL
+        for (int k = 0; k < 6; ++k) f.la[k] = 0.0;
+    }
+}
+/* dense access L(k,l), k,l in 0..5 (compile-time indices) */
+KFPOS_FN double L9(const Factor9 &f, int k, int l) {
+    if (k < 3 && l < 3) {
+        if (k < l) return 0.0;
+        /* lower packed {00,10,20,11,21,22} */
+        return f.lr[l == 0 ? k : (l == 1 ? 2 + k : 5)];
+    }
+    if (k >= 3 && l >= 3) {
+        const int i = k - 3, j = l - 3;
+        if (i > j) return 0.0;
+        return f.la[i == 0 ? j : (i == 1 ? 2 + j : 5)];
+    }
+    return 0.0;
+}
+
+struct Iekf9Out {
+    double x[9];
+    double mrlast[6], dlast[3];
+    double cost;
+    int gain_iters, ml_iters;
+    uint32_t flags;
+};
+
+/* kalmanStep3D (KalmanFilterTOAIMU.cpp:242-340, with the 3-token repair), first part (:268-276): ML
+ * position -> observation covariance of the ranging rows. Independent of P. */
+template <class SC>
+KFPOS_FN void iekf9_weights(const double xhat[9], SC &sc, const Params &pr, bool has_ranging, int n_used,
+                            Iekf9Out &o) {
+    o.flags = (has_ranging && n_used < 4) ? ST_FEW_RANGES : 0u;
+    o.ml_iters = 0;
+    if (has_ranging) {
+        double pml[3] = {xhat[0], xhat[1], xhat[2]}, e_ml;
+        set_weights_ml(sc, pr, 0ull);
+        o.ml_iters = ml_estimate(pml, sc, pr, 0ull, n_used, e_ml); /* no NaN fallback in this filter */
+        if (ml_covariance_throws(sc, pr, 0ull, n_used, e_ml)) o.flags |= ST_UPDATE_SKIPPED;
+        set_weights_iekf(sc, pr, e_ml, 0ull);
+    }
+}
+
+/* second part (:296-336): the IEKF loop, up to the covariance update */
+/* DIAG: the accelerometer covariance of every lane of the wavefront is diagonal (the usual case: sensor_msgs::Imu
+ * carries diag covariances), so Sigma^-1 and M_a = D Sigma^-1 D are diagonal: their 3x3 products collapse to
+ * scalings (about 90 of the 725 instructions of an iteration). Same results: the skipped terms are exact zeros. */
+template <bool DIAG, class SC>
+KFPOS_FN void iekf9(const double xhat[9], const Cov<9, true> &P, SC &sc, const Params &pr,
+                    bool has_ranging, const Imu &imu, int max_steps, double tol, Iekf9Out &o) {
+    const uint64_t drop = has_ranging ? 0ull : ~0ull;
+    double p[3] = {xhat[0], xhat[1], xhat[2]}, acc[3] = {xhat[6], xhat[7], xhat[8]};
+    double de[6] = {0, 0, 0, 0, 0, 0}; /* delta on the updated components (position, acceleration) */
+    double wl[6] = {0, 0, 0, 0, 0, 0};
+    double qd = 0.0, cost = 1e20;
+    const bool pivot = has_ranging && illconditioned(sc, pr, P);
+    KFPOS_UNROLL
+    for (int k = 0; k < 6; ++k) o.mrlast[k] = 0.0;
+    o.dlast[0] = o.dlast[1] = o.dlast[2] = 0.0;
+    o.gain_iters = 0;
+    for (int iter = 0; iter < max_steps; ++iter) {
+        double c = qd, m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0, u0 = 0, u1 = 0, u2 = 0;
+        if (has_ranging) {
+            for_anchors<SC>(pr, [&](int a) {
+                const double dx = p[0] - pr.anchors[3 * a], dy = p[1] - pr.anchors[3 * a + 1],
+                             dz = p[2] - pr.anchors[3 * a + 2];
+                double d, invd;
+                kf_sqrt_rsqrt_sweep(dx * dx + dy * dy + dz * dz, d, invd);
+                const double w = sc.W(a), y = sc.R(a) - d; /* weight 0 = absent / dropped range (set_weights_iekf) */
+                const double yw = y * w;
+                c += y * yw;
+                const double gx = dx * invd, gy = dy * invd, gz = dz * invd;
+                u0 += gx * yw; u1 += gy * yw; u2 += gz * yw;
+                const double wx = w * gx, wy = w * gy, wz = w * gz;
+                m0 += wx * gx; m1 += wx * gy; m2 += wx * gz;
+                m3 += wy * gy; m4 += wy * gz; m5 += wz * gz;
+            });
+        }
+        /* u_r = G' R^-1 (y - G delta_p) = G' R^-1 y - M_r delta_p: the delta term once per pass */
+        const double m[6] = {m0, m1, m2, m3, m4, m5},
+                     u[3] = {u0 - (m0 * de[0] + m1 * de[1] + m2 * de[2]), u1 - (m1 * de[0] + m3 * de[1] + m4 * de[2]),
+                             u2 - (m2 * de[0] + m4 * de[1] + m5 * de[2])};
+        /* IMU rows: y_a = z_a - a, cost += y_a' Sigma^-1 y_a, u_a = D Sigma^-1 (y_a - D delta_a),
+         * M_a = D Sigma^-1 D with D = diag(a) (sic, KalmanFilterTOAIMU.cpp:441-473) */
+        double ua[3] = {0, 0, 0}, ma[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+        if (imu.has) {
+            const double ya[3] = {imu.acc[0] - acc[0], imu.acc[1] - acc[1], imu.acc[2] - acc[2]};
+            const double va[3] = {ya[0] - acc[0] * de[3], ya[1] - acc[1] * de[4], ya[2] - acc[2] * de[5]};
+            if constexpr (DIAG) {
+                const double wd[3] = {imu.wi[0], imu.wi[3], imu.wi[5]};
+                KFPOS_UNROLL
+                for (int i = 0; i < 3; ++i) { /* same operation order as the full path: bit-identical results */
+                    const double wy = wd[i] * ya[i];
+                    c += ya[i] * wy;
+                    ua[i] = acc[i] * (wd[i] * va[i]);
+                    ma[i][i] = acc[i] * acc[i] * wd[i];
+                }
+            } else {
+                const double wm[3][3] = {{imu.wi[0], imu.wi[1], imu.wi[2]},
+                                         {imu.wi[1], imu.wi[3], imu.wi[4]},
+                                         {imu.wi[2], imu.wi[4], imu.wi[5]}};
+                KFPOS_UNROLL
+                for (int i = 0; i < 3; ++i) {
+                    const double wy = wm[i][0] * ya[0] + wm[i][1] * ya[1] + wm[i][2] * ya[2];
+                    c += ya[i] * wy;
+                    ua[i] = acc[i] * (wm[i][0] * va[0] + wm[i][1] * va[1] + wm[i][2] * va[2]);
+                    KFPOS_UNROLL
+                    for (int j = 0; j < 3; ++j) ma[i][j] = acc[i] * acc[j] * wm[i][j];
+                }
+            }
+        }
+        if (fabs(cost - c) / cost < tol) break; /* KalmanFilterTOAIMU.cpp:316 */
+        cost = c;
+        KFPOS_UNROLL
+        for (int k = 0; k < 6; ++k) o.mrlast[k] = m[k];
+        o.dlast[0] = acc[0]; o.dlast[1] = acc[1]; o.dlast[2] = acc[2];
+
+        /* w = (I + M P_ee)^-1 [u_r; u_a], M = blockdiag(M_r, M_a), by 3x3 blocks:
+         *   [A11 A12; A21 A22] = I + [M_r Ppp, M_r Ppa; M_a Pap, M_a Paa]
+         * A11 and the Schur complement are inverted through their adjugates (both have real
+         * eigenvalues >= 1: products of PSD matrices shifted by I). */
+        const double mr[3][3] = {{m[0], m[1], m[2]}, {m[1], m[3], m[4]}, {m[2], m[4], m[5]}};
+        double a11[9], a12[3][3], a21[3][3], a22[3][3];
+        KFPOS_UNROLL
+        for (int i = 0; i < 3; ++i) {
+            KFPOS_UNROLL
+            for (int j = 0; j < 3; ++j) {
+                a11[3 * i + j] = (i == j ? 1.0 : 0.0) + mr[i][0] * P(0, j) + mr[i][1] * P(1, j) + mr[i][2] * P(2, j);
+                a12[i][j] = mr[i][0] * P(0, 6 + j) + mr[i][1] * P(1, 6 + j) + mr[i][2] * P(2, 6 + j);
+                if constexpr (DIAG) {
+                    a21[i][j] = ma[i][i] * P(6 + i, j);
+                    a22[i][j] = (i == j ? 1.0 : 0.0) + ma[i][i] * P(6 + i, 6 + j);
+                } else {
+                    a21[i][j] = ma[i][0] * P(6, j) + ma[i][1] * P(7, j) + ma[i][2] * P(8, j);
+                    a22[i][j] = (i == j ? 1.0 : 0.0) + ma[i][0] * P(6, 6 + j) + ma[i][1] * P(7, 6 + j) + ma[i][2] * P(8, 6 + j);
+                }
+            }
+        }
+        if (!pivot) {
+            double adj[9];
+            const double id1 = kf_rcp(gen3_adjugate(a11, adj));
+            double xx[3][3], y1[3]; /* X = A11^-1 A12, y1 = A11^-1 u_r */
+            KFPOS_UNROLL
+            for (int i = 0; i < 3; ++i) {
+                y1[i] = (adj[3 * i] * u[0] + adj[3 * i + 1] * u[1] + adj[3 * i + 2] * u[2]) * id1;
+                KFPOS_UNROLL
+                for (int j = 0; j < 3; ++j)
+                    xx[i][j] = (adj[3 * i] * a12[0][j] + adj[3 * i + 1] * a12[1][j] + adj[3 * i + 2] * a12[2][j]) * id1;
+            }
+            double sc9[9], rhs[3]; /* Schur complement A22 - A21 X, rhs u_a - A21 y1 */
+            KFPOS_UNROLL
+            for (int i = 0; i < 3; ++i) {
+                rhs[i] = ua[i] - (a21[i][0] * y1[0] + a21[i][1] * y1[1] + a21[i][2] * y1[2]);
+                KFPOS_UNROLL
+                for (int j = 0; j < 3; ++j)
+                    sc9[3 * i + j] = a22[i][j] - (a21[i][0] * xx[0][j] + a21[i][1] * xx[1][j] + a21[i][2] * xx[2][j]);
+            }
+            const double id2 = kf_rcp(gen3_adjugate(sc9, adj));
+            KFPOS_UNROLL
+            for (int i = 0; i < 3; ++i)
+                wl[3 + i] = (adj[3 * i] * rhs[0] + adj[3 * i + 1] * rhs[1] + adj[3 * i + 2] * rhs[2]) * id2;
+            KFPOS_UNROLL
+            for (int i = 0; i < 3; ++i) wl[i] = y1[i] - (xx[i][0] * wl[3] + xx[i][1] * wl[4] + xx[i][2] * wl[5]);
+        } else { /* ill-conditioned step: the same block elimination with pivoted 3x3 solves instead of adjugates */
+            double b4[12], x4[12]; /* [A12 | u_r] -> [X | y1] = A11^-1 [A12 | u_r] */
+            KFPOS_UNROLL
+            for (int i = 0; i < 3; ++i) {
+                KFPOS_UNROLL
+                for (int j = 0; j < 3; ++j) b4[4 * i + j] = a12[i][j];
+                b4[4 * i + 3] = u[i];
+            }
+            gauss_solve<3, 4>(a11, b4, x4);
+            double s9[9], r3[3], wa[3];
+            KFPOS_UNROLL
+            for (int i = 0; i < 3; ++i) {
+                r3[i] = ua[i] - (a21[i][0] * x4[3] + a21[i][1] * x4[7] + a21[i][2] * x4[11]);
+                KFPOS_UNROLL
+                for (int j = 0; j < 3; ++j)
+                    s9[3 * i + j] = a22[i][j] - (a21[i][0] * x4[j] + a21[i][1] * x4[4 + j] + a21[i][2] * x4[8 + j]);
+            }
+            gauss_solve<3, 1>(s9, r3, wa);
+            KFPOS_UNROLL
+            for (int i = 0; i < 3; ++i) {
+                wl[3 + i] = wa[i];
+                wl[i] = x4[4 * i + 3] - (x4[4 * i] * wa[0] + x4[4 * i + 1] * wa[1] + x4[4 * i + 2] * wa[2]);
+            }
+        }
+        /* x_e = xhat_e + P_ee w ; delta_e = -P_ee w ; delta' pinv(P) delta = w . P_ee w */
+        qd = 0.0;
+        KFPOS_UNROLL
+        for (int i = 0; i < 6; ++i) {
+            double v = 0.0;
+            KFPOS_UNROLL
+            for (int k = 0; k < 6; ++k) v += P(e9(i), e9(k)) * wl[k];
+            de[i] = -v;
+            qd += wl[i] * v;
+            if (i < 3) p[i] = xhat[i] + v;
+            else acc[i - 3] = xhat[3 + i] + v;
+        }
+        o.gain_iters++;
+    }
+    KFPOS_UNROLL
+    for (int i = 0; i < 9; ++i) {
+        double v = 0.0;
+        KFPOS_UNROLL
+        for (int k = 0; k < 6; ++k) v += P(i, e9(k)) * wl[k];
+        o.x[i] = xhat[i] + v;
+    }
+    o.cost = cost;
+}
+
+/* P <- (I - K H) P (KalmanFilterTOAIMU.cpp:338) as six rank-1 downdates along the columns of
+ * E' L (unit-noise pseudo-measurements): P -= (P t)(P t)' / (1 + t' P t). */
+KFPOS_FN void cov_update9(Cov<9, true> &P, const double mr[6], const double d[3], const Imu &imu) {
+    Factor9 f;
+    factor9(mr, d, imu, f);
+    KFPOS_UNROLL
+    for (int k = 0; k < 6; ++k) {
+        double pt[9], s = 1.0;
+        KFPOS_UNROLL
+        for (int i = 0; i < 9; ++i) {
+            double v = 0.0;
+            KFPOS_UNROLL
+            for (int l = 0; l < 6; ++l) {
+                const bool nz = (l < 3 && k < 3 && l >= k) || (l >= 3 && k >= 3 && l <= k);
+                if (nz) v += P(i, e9(l)) * L9(f, l, k);
+            }
+            pt[i] = v;
+        }
+        KFPOS_UNROLL
+        for (int l = 0; l < 6; ++l) {
+            const bool nz = (l < 3 && k < 3 && l >= k) || (l >= 3 && k >= 3 && l <= k);
+            if (nz) s += L9(f, l, k) * pt[e9(l)];
+        }
+        const double is = kf_rcp(s);
+        KFPOS_UNROLL
+        for (int i = 0; i < 9; ++i) {
+            const double pi = pt[i] * is;
+            KFPOS_UNROLL
+            for (int j = i; j < 9; ++j) P(i, j) -= pi * pt[j];
+        }
+    }
+}
+
+/* KalmanFilterTOAIMU::estimatePositionKF (KalmanFilterTOAIMU.cpp:100-195) for one tag.
+ * has_ranging = false is the IMU-only call of newIMUMeasurement (:91). */
+template <class SC>
+KFPOS_FN uint32_t step_imu9(Tag9 &tg, SC &sc, const Params &pr, double dt,
+                                   bool has_ranging, const Imu &imu) {
+    const int n_valid = has_ranging ? count_used(sc, pr, 0) : 0;
+    if (!pr.use_init_pos && (isnan(tg.pos[0]) || isnan(tg.pos[1]))) { /* :121-122, z is not tested */
+        if (!has_ranging) return 0;
+        if (n_valid < 4) return ST_FEW_RANGES;
+        double p[3] = {1.0, 1.0, 4.0}, sse, c[6];
+        set_weights_ml(sc, pr, 0ull);
+        const int it = ml_estimate(p, sc, pr, 0, n_valid, sse);
+        if (ml_covariance_throws(sc, pr, 0, n_valid, sse)) return ST_UPDATE_SKIPPED; /* reference: abort */
+        if (!ml_covariance(p, sc, pr, sse, c)) return ST_UPDATE_SKIPPED;
+        tg.pos[0] = p[0]; tg.pos[1] = p[1]; tg.pos[2] = p[2];
+        tg.P(0, 0) = c[0]; tg.P(0, 1) = c[1]; tg.P(1, 1) = c[3]; /* xy block only, :134-137 */
+        return pack_status(ST_ML_INIT, 0, it, -1);
+    }
+    const double c = dt * dt / 2;
+    double xhat[9];
+    KFPOS_UNROLL
+    for (int k = 0; k < 3; ++k) { /* acceleration restarts at 0 */
+        xhat[k] = tg.pos[k] + dt * tg.vel[k] + c * 0.0;
+        xhat[3 + k] = tg.vel[k] + dt * 0.0;
+        xhat[6 + k] = 0.0;
+    }
+    Iekf9Out o;
+    iekf9_weights(xhat, sc, pr, has_ranging, n_valid, o); /* needs position + epoch only ... */
+    predict9(tg.P, dt, pr.jolt);                          /* ... so the covariance is first touched here */
+    /* The 9-state filter has no try/catch: the reference node aborts here. This core keeps the predicted
+     * covariance and reports the tag instead. */
+    if (o.flags & ST_UPDATE_SKIPPED) return ST_UPDATE_SKIPPED;
+    /* exact zeros only: the whitener of a diagonal covariance produces them */
+    const bool diag = !imu.has || (imu.wi[1] == 0.0 && imu.wi[2] == 0.0 && imu.wi[4] == 0.0);
+    if (KFPOS_WAVE_ALL(diag)) iekf9<true>(xhat, tg.P, sc, pr, has_ranging, imu, 20, 1e-4, o);
+    else iekf9<false>(xhat, tg.P, sc, pr, has_ranging, imu, 20, 1e-4, o);
+    cov_update9(tg.P, o.mrlast, o.dlast, imu);
+    KFPOS_UNROLL
+    for (int k = 0; k < 3; ++k) { tg.pos[k] = o.x[k]; tg.vel[k] = o.x[3 + k]; } /* :189-194 */
+    return pack_status(o.flags, o.gain_iters, o.ml_iters, -1);
+}
+
+/* getPose (KalmanFilterTOAIMU.cpp:476-510): predicted position / velocity and the position block */
+KFPOS_FN void pose9(const Tag9 &tg, double t, double jolt, double pos[3], double vel[3], double cov[9]) {
+    const double c = t * t / 2, t3 = (t * t * t) / 6;
+    KFPOS_UNROLL
+    for (int i = 0; i < 3; ++i) {
+        pos[i] = tg.pos[i] + t * tg.vel[i];
+        vel[i] = tg.vel[i];
+        KFPOS_UNROLL
+        for (int j = 0; j < 3; ++j) {
+            const Cov<9, true> &P = tg.P;
+            const double xpp = P(i, j) + t * P(3 + i, j) + c * P(6 + i, j);
+            const double xpv = P(i, 3 + j) + t * P(3 + i, 3 + j) + c * P(6 + i, 3 + j);
+            const double xpa = P(i, 6 + j) + t * P(3 + i, 6 + j) + c * P(6 + i, 6 + j);
+            cov[3 * i + j] = xpp + t * xpv + c * xpa + (i == j ? jolt * t3 * t3 : 0.0);
+        }
+    }
+}
+
+} // namespace kfpos
+#endif

@@ -1,0 +1,240 @@
+/*
+ * kfpos_core_ml.h -- part of kfpos_core.h (include that, not this): per-tag arithmetic shared by the HIP kernels and
+ * the host emulation of the tests.
+ * Gauss-Newton multilateration (MLLocation::estimatePosition, MLLocation.cpp:153-257), its covariance, the top-N
+ * composition and the standalone ML estimator (ALGORITHM_ML).
+ */
+#ifndef KFPOS_CORE_ML_H
+#define KFPOS_CORE_ML_H
+
+namespace kfpos {
+
+/* ------------------------------------------------------------------ MLLocation::estimatePosition */
+/* One sweep over the anchors at position p: weighted cost sum (r-d)^2/e, unweighted SSE
+ * (estimationError, MLLocation.cpp:263-278), gradient g and Hessian-like Hs of
+ * MLLocation.cpp:174-204 (Hs symmetric, packed {00,01,02,11,12,22}). */
+template <class SC>
+KFPOS_FN void ml_sweep(const double p[3], const SC &sc, const Params &pr, uint64_t drop,
+                              double &cw, double &sse, double g[3], double hs[6]) {
+    double cw_ = 0.0, sse_ = 0.0, g0 = 0.0, g1 = 0.0, g2 = 0.0;
+    double h0 = 0.0, h1 = 0.0, h2 = 0.0, h3 = 0.0, h4 = 0.0, h5 = 0.0;
+    for_anchors<SC>(pr, [&](int a) {
+        /* branch-free: an absent / dropped range gets weight 0 (select, so a garbage errorEstimation of a
+         * missing range never enters), which keeps the unrolled anchors in one basic block and lets the
+         * scheduler interleave their independent rsqrt chains */
+        const bool on = used(sc, a, drop);
+        const double r = sc.R(a), w = sc.W(a); /* 0 for an absent / dropped range (set_weights_*) */
+        double bx, by, bz;
+        anchor_of(sc, pr, a, bx, by, bz);
+        const double dx = bx - p[0], dy = by - p[1], dz = bz - p[2];
+        double d, invd;
+        kf_sqrt_rsqrt_sweep(dx * dx + dy * dy + dz * dz, d, invd);
+        const double rd = r - d;
+        cw_ += rd * rd * w;
+        sse_ += on ? rd * rd : 0.0;
+        const double gi = rd * invd * w;
+        g0 += gi * dx;
+        g1 += gi * dy;
+        g2 += gi * dz;
+        const double q = r * invd;
+        const double c0 = w * (1.0 - q), c1 = w * q * invd * invd;
+        h0 += c0 + c1 * dx * dx;
+        h1 += c1 * dx * dy;
+        h2 += c1 * dx * dz;
+        h3 += c0 + c1 * dy * dy;
+        h4 += c1 * dy * dz;
+        h5 += c0 + c1 * dz * dz;
+    });
+    cw = group_sum(sc, cw_); sse = group_sum(sc, sse_);
+    g[0] = group_sum(sc, g0); g[1] = group_sum(sc, g1); g[2] = group_sum(sc, g2);
+    hs[0] = group_sum(sc, h0); hs[1] = group_sum(sc, h1); hs[2] = group_sum(sc, h2);
+    hs[3] = group_sum(sc, h3); hs[4] = group_sum(sc, h4); hs[5] = group_sum(sc, h5);
+}
+
+/* SSE only (estimationError at a given position) */
+template <class SC>
+KFPOS_FN double ml_sse(const double p[3], const SC &sc, const Params &pr, uint64_t drop) {
+    double sse = 0.0;
+    for_anchors<SC>(pr, [&](int a) {
+        double bx, by, bz;
+        anchor_of(sc, pr, a, bx, by, bz);
+        const double dx = bx - p[0], dy = by - p[1], dz = bz - p[2];
+        double d, invd;
+        kf_sqrt_rsqrt(dx * dx + dy * dy + dz * dz, d, invd);
+        const double rd = d - sc.R(a);
+        sse += used(sc, a, drop) ? rd * rd : 0.0;
+    });
+    return group_sum(sc, sse);
+}
+
+/* Gauss-Newton loop of MLLocation.cpp:164-225. p: seed in, estimate out. Requires sc.w = 1/e.
+ * Returns the iteration count; sse_out = estimationError at the result. With n_used < 4 the
+ * seed is returned untouched (MLLocation.cpp:158-161). The step p - Hs^-1 g equals the
+ * reference's solve(Hs, Hs p - g). One sweep per pass yields the cost of the point just reached
+ * and the gradient/Hessian for the next step (the reference evaluates them in two passes). */
+template <class SC>
+KFPOS_FN int ml_estimate(double p[3], const SC &sc, const Params &pr, uint64_t drop,
+                                int n_used, double &sse_out) {
+    if (n_used < 4) {
+        sse_out = (n_used == 0) ? -1.0 : ml_sse(p, sc, pr, drop);
+        return 0;
+    }
+    double cost = 1e20, newCost = 1.0, cw, sse, g[3], hs[6], c[6];
+    int iter = 0;
+    for (;;) {
+        ml_sweep(p, sc, pr, drop, cw, sse, g, hs);
+        if (iter > 0) newCost = cw;
+        if (!((fabs(cost - newCost) / cost > 1e-3) && (iter < 10000))) break; /* MLLocation.cpp:168 */
+        iter += 1;
+        cost = newCost;
+        const double idet = kf_rcp(sym3_cofactors(hs, c));
+        p[0] -= (c[0] * g[0] + c[1] * g[1] + c[2] * g[2]) * idet;
+        p[1] -= (c[1] * g[0] + c[3] * g[1] + c[4] * g[2]) * idet;
+        p[2] -= (c[2] * g[0] + c[4] * g[1] + c[5] * g[2]) * idet;
+    }
+    sse_out = sse;
+    return iter;
+}
+
+/* covariance of the ML estimate, inv(J' diag(max(e, e_ML))^-1 J) (MLLocation.cpp:229-252);
+ * symmetric 3x3 packed. Only the ML initialisation uses it. */
+template <class SC>
+KFPOS_FN bool ml_covariance(const double p[3], const SC &sc, const Params &pr, double sse,
+                                   double cov[6]) {
+    double m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0, c[6];
+    for_anchors<SC>(pr, [&](int a) {
+        if (!used(sc, a, 0)) return;
+        double bx, by, bz;
+        anchor_of(sc, pr, a, bx, by, bz);
+        const double dx = p[0] - bx, dy = p[1] - by, dz = p[2] - bz;
+        const double invd = 1.0 / sqrt(dx * dx + dy * dy + dz * dz);
+        const double w = 1.0 / stdmax(sc.E(a), sse);
+        const double gx = dx * invd, gy = dy * invd, gz = dz * invd;
+        m0 += w * gx * gx; m1 += w * gx * gy; m2 += w * gx * gz;
+        m3 += w * gy * gy; m4 += w * gy * gz; m5 += w * gz * gz;
+    });
+    const double m[6] = {group_sum(sc, m0), group_sum(sc, m1), group_sum(sc, m2),
+                         group_sum(sc, m3), group_sum(sc, m4), group_sum(sc, m5)};
+    const double det = sym3_cofactors(m, c);
+    const double idet = 1.0 / det;
+    KFPOS_UNROLL
+    for (int k = 0; k < 6; ++k) cov[k] = c[k] * idet;
+    return det != 0.0; /* inv() of an exactly singular J' W J throws (anchors and seed in one plane / on one line) */
+}
+
+/* MLLocation::estimatePosition ends with inv(diagmat(max(e_i, e_ML))) and inv(J' W J) (MLLocation.cpp:248-252).
+ * The first one throws std::runtime_error when an entry is exactly 0 -- which is what an errorEstimation of 0
+ * leads to: the 1/e weights make the ML position NaN, e_ML is NaN, std::max(e_i, NaN) = e_i = 0. The
+ * 6-state filter swallows the exception and skips the update (KalmanFilterTOA.cpp:151-153). */
+template <class SC>
+KFPOS_FN bool ml_covariance_throws(const SC &sc, const Params &pr, uint64_t drop, int n_used, double sse,
+                                   int min_used = 4) {
+    if (n_used < min_used) return false; /* estimatePosition returned before getting there */
+    bool bad = false;
+    for_anchors<SC>(pr, [&](int a) { bad = bad || (used(sc, a, drop) && stdmax(sc.E(a), sse) == 0.0); });
+    if constexpr (SC::COOP) bad = group_sum(sc, bad ? 1.0 : 0.0) > 0.0;
+    return bad;
+}
+
+/* Not detected in the per-epoch solves: the second inverse, inv(J' W J), also throws when J' W J is EXACTLY singular
+ * (all used anchors and the estimate on one line / in one plane with coordinates symmetric enough that every
+ * cancellation is exact -- anchors at (0,0) and (10,10) with the estimate on the diagonal). The update path does not
+ * form that covariance (an extra sweep per solve, 3-14 % of a step, for a measure-zero geometry); the ML
+ * initialisation, which needs the covariance anyway, does report it (ml_covariance / ml2d_covariance). */
+/* Working weights. An absent or dropped range gets weight 0 HERE (a select, so a garbage errorEstimation of a
+ * missing range never enters): the sweeps, which run 10-60 times per step, then read the weight as it is. */
+template <class SC>
+KFPOS_FN void set_weights_ml(SC &sc, const Params &pr, uint64_t drop) {
+    for_anchors<SC>(pr, [&](int a) { sc.setW(a, used(sc, a, drop) ? kf_rcp(sc.E(a)) : 0.0); });
+}
+template <class SC>
+KFPOS_FN void set_weights_iekf(SC &sc, const Params &pr, double e_ml, uint64_t drop) {
+    for_anchors<SC>(pr, [&](int a) { /* KalmanFilterTOA.cpp:281 */
+        sc.setW(a, used(sc, a, drop) ? kf_rcp(stdmax(e_ml, sc.E(a))) : 0.0);
+    });
+}
+
+/* Top-N composition (BASELINE config 5; MLLocation.cpp:284-300, 325-339): rank the residual^2
+ * at the ML position of all ranges, drop the min(n-4, N) largest. Returns the drop mask. */
+template <class SC>
+KFPOS_FN uint64_t topn_mask(const double seed[3], SC &sc, const Params &pr, int n_valid) {
+    int ndrop = n_valid - 4 < pr.top_n ? n_valid - 4 : pr.top_n;
+    if (ndrop <= 0) return 0;
+    double p[3] = {seed[0], seed[1], seed[2]}, sse;
+    set_weights_ml(sc, pr, 0ull);
+    ml_estimate(p, sc, pr, 0, n_valid, sse);
+    uint64_t drop = 0;
+    for (int k = 0; k < ndrop; ++k) {
+        double worst = -1.0;
+        int wi = -1;
+        for_anchors<SC>(pr, [&](int a) {
+            const double dx = pr.anchors[3 * a] - p[0], dy = pr.anchors[3 * a + 1] - p[1],
+                         dz = pr.anchors[3 * a + 2] - p[2];
+            double d, invd;
+            kf_sqrt_rsqrt(dx * dx + dy * dy + dz * dz, d, invd);
+            const double rd = d - sc.R(a);
+            const bool take = used(sc, a, drop) && (rd * rd > worst);
+            worst = take ? rd * rd : worst;
+            wi = take ? a : wi;
+        });
+        if (wi < 0) break;
+        drop |= 1ull << wi;
+    }
+    return drop;
+}
+
+/* ================================================================== standalone ML estimator (ALGORITHM_ML) */
+/* MLLocation::newTOAMeasurement + getPose (MLLocation.cpp:421-486), variant NORMAL 3-D or IGNORE_N
+ * (estimatePositionIgnoreN, :307-347): solve from the fixed seed (_previousEstimation is never updated),
+ * optionally drop the min(n-4, N) largest residuals and solve again, return position + 3x3 covariance. */
+template <class SC>
+KFPOS_FN uint32_t step_ml(double pos[3], double cov[6], SC &sc, const Params &pr, const double seed[3]) {
+    int n_valid = count_used(sc, pr, 0);
+    if (n_valid < 4) { /* estimatePosition returns the seed; its covariance is empty (getPose would abort) */
+        KFPOS_UNROLL
+        for (int k = 0; k < 3; ++k) pos[k] = seed[k];
+        KFPOS_UNROLL
+        for (int k = 0; k < 6; ++k) cov[k] = NAN;
+        return ST_FEW_RANGES;
+    }
+    uint64_t drop = 0;
+    if (pr.top_n > 0) {
+        drop = topn_mask(seed, sc, pr, n_valid); /* first solve + ranking */
+        /* the first solve throws exactly when a used errorEstimation is 0 (its sse is NaN then) */
+        if (ml_covariance_throws(sc, pr, 0, n_valid, NAN)) return ST_UPDATE_SKIPPED;
+        n_valid = count_used(sc, pr, drop);
+    }
+    double p[3] = {seed[0], seed[1], seed[2]}, sse;
+    set_weights_ml(sc, pr, drop);
+    const int it = ml_estimate(p, sc, pr, drop, n_valid, sse);
+    if (ml_covariance_throws(sc, pr, drop, n_valid, sse)) return ST_UPDATE_SKIPPED;
+    double c[6];
+    /* covariance over the kept ranges only */
+    {
+        double m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0, cf[6];
+        for_anchors<SC>(pr, [&](int a) {
+            const bool on = used(sc, a, drop);
+            const double dx = p[0] - pr.anchors[3 * a], dy = p[1] - pr.anchors[3 * a + 1],
+                         dz = p[2] - pr.anchors[3 * a + 2];
+            const double invd = 1.0 / sqrt(dx * dx + dy * dy + dz * dz);
+            const double w = on ? 1.0 / stdmax(sc.E(a), sse) : 0.0;
+            const double gx = dx * invd, gy = dy * invd, gz = dz * invd;
+            m0 += w * gx * gx; m1 += w * gx * gy; m2 += w * gx * gz;
+            m3 += w * gy * gy; m4 += w * gy * gz; m5 += w * gz * gz;
+        });
+        const double m[6] = {m0, m1, m2, m3, m4, m5};
+        const double det = sym3_cofactors(m, cf);
+        if (det == 0.0) return ST_UPDATE_SKIPPED; /* inv() of an exactly singular J' W J throws */
+        const double idet = 1.0 / det;
+        KFPOS_UNROLL
+        for (int k = 0; k < 6; ++k) c[k] = cf[k] * idet;
+    }
+    KFPOS_UNROLL
+    for (int k = 0; k < 3; ++k) pos[k] = p[k];
+    KFPOS_UNROLL
+    for (int k = 0; k < 6; ++k) cov[k] = c[k];
+    return pack_status(0, 0, it, -1);
+}
+
+} // namespace kfpos
+#endif
