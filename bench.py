@@ -228,7 +228,8 @@ def main():
                                    "covariance (KFPOS_STORE_MIXED: a 24-bit covariance misses the 1e-6 m bar)",
                        "tags_per_gpu": T, "anchors": ANCHORS, "total_tags": T * world,
                        "epochs_per_launch": E, "pose_output": "every epoch ([S][3][T] f64)",
-                       "pose_gather": "rccl all_gather per launch, overlapped" if world > 1 else "none (single GPU)"},
+                       "pose_gather": (("rccl" if backend == "nccl" else backend + " (rehearsal)") +
+                                       " all_gather per launch, overlapped") if world > 1 else "none (single GPU)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_step_imu9<double,float,8>", "kernel_us_per_launch": per_launch_s * 1e6,
