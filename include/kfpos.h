@@ -56,9 +56,13 @@ extern "C" {
 #define KFPOS_MAX_ANCHORS 64 /* MAX_NUM_ANCS, Posgenerator.h:74 */
 
 /* ---- per-tag status word ---- */
-#define KFPOS_ST_UPDATE_SKIPPED 0x01u /* the std::runtime_error the reference swallows (KalmanFilterTOA.cpp:151-153) */
+#define KFPOS_ST_UPDATE_SKIPPED 0x01u /* the std::runtime_error the reference swallows (KalmanFilterTOA.cpp:151-153); the
+                                         9-state and planar filters have no try/catch (the node would abort): here the
+                                         tag keeps its predicted covariance and reports this bit. Also: ML initialisation
+                                         whose covariance is exactly singular, planar sensor row with zero variance */
 #define KFPOS_ST_ML_FALLBACK    0x02u /* ML position NaN -> predicted position (KalmanFilterTOA.cpp:270-272) */
-#define KFPOS_ST_FEW_RANGES     0x04u /* < 4 ranges this epoch: ML returned its seed (MLLocation.cpp:158-161) */
+#define KFPOS_ST_FEW_RANGES     0x04u /* < 4 ranges this epoch (< 3 for the planar filter's 2-D solve): ML returned its seed
+                                         (MLLocation.cpp:158-161, :54-58) */
 #define KFPOS_ST_ML_INIT        0x08u /* this epoch was consumed by the ML initialisation (KalmanFilterTOA.cpp:90-108) */
 #define KFPOS_ST_NOT_STARTED    0x10u /* getPose() == false: no measurement yet (KalmanFilterTOA.cpp:442-447) */
 #define KFPOS_ST_NONFINITE      0x20u /* state not finite after the call */
