@@ -7,6 +7,7 @@
  *   KalmanFilterTOA               src/kfpos/algorithms/KalmanFilterTOA.h:18-54
  *   KalmanFilterTOAIMU            src/kfpos/algorithms/KalmanFilterTOAIMU.h:16-78
  *   KalmanFilter                  src/kfpos/algorithms/KalmanFilter.h:29-133 (8-state planar filter, ALGORITHM_KF)
+ *   MLLocation                    src/kfpos/algorithms/MLLocation.h:26-70 as an estimator (ALGORITHM_ML; 3-D, variants 0 and 1)
  *   Vector3 / VectorDim3 / Beacon src/kfpos/algorithms/sensor_types.h:7-25
  * Differences, all at the type level: Vector3::covarianceMatrix is a plain row-major array with its
  * dimension (the reference embeds an arma::mat); the estimator reads time from an injectable clock
@@ -118,7 +119,7 @@ public:
 
 protected:
     SingleTagFilter(int model, double accelNoise, double jolt, bool ignoreWorst, double costThreshold,
-                    bool fixed, const Vector3 *init) {
+                    bool fixed, const Vector3 *init, int topN = 0) {
         kfpos_config c;
         std::memset(&c, 0, sizeof(c));
         c.model = model;
@@ -129,6 +130,7 @@ protected:
         c.jolt = jolt;
         c.ignore_worst = ignoreWorst ? 1 : 0;
         c.cost_threshold = costThreshold;
+        c.top_n = topN;
         c.use_init_pos = fixed ? 1 : 0;
         if (init) { c.init_pos[0] = init->x; c.init_pos[1] = init->y; c.init_pos[2] = init->z; }
         check(kfpos_create(&c, &h_));
@@ -212,6 +214,45 @@ protected:
         }
         pose.covarianceMatrix[7 * 9 + 7] = P[8 * 9 + 8];
     }
+};
+
+/* ---- ALGORITHM_ML: MLLocation as the estimator (MLLocation.cpp:421-486) ---- */
+#define ML_VARIANT_NORMAL 0   /* MLLocation.h:5-7 */
+#define ML_VARIANT_IGNORE_N 1
+#define ML_VARIANT_BEST 2
+
+class MLLocation : public SingleTagFilter {
+public:
+    /* _previousEstimation = {1,1,4} (MLLocation.cpp:3-12) */
+    MLLocation() : SingleTagFilter(KFPOS_MODEL_ML, 0.0, 0.0, false, 0.0, false, nullptr) {}
+    /* MLLocation.cpp:14-22. Offered: the 3-D solver, variants NORMAL and IGNORE_N. The 2-D variant indexes (0,2) of a
+     * 2x2 covariance in getPose (:456-464) and BEST erases through shifting indices (:379-383): neither has a
+     * defined result in the reference, both are refused here. */
+    MLLocation(bool use2d, int variant, int numRangingsToIgnore, const Vector3 &previousEstimation)
+        : SingleTagFilter(KFPOS_MODEL_ML, 0.0, 0.0, false, 0.0, true, &previousEstimation,
+                          variant == ML_VARIANT_IGNORE_N ? numRangingsToIgnore : 0) {
+        if (use2d) throw std::invalid_argument("MLLocation: use2d has no defined result in the reference (getPose, MLLocation.cpp:456-464)");
+        if (variant != ML_VARIANT_NORMAL && variant != ML_VARIANT_IGNORE_N)
+            throw std::invalid_argument("MLLocation: variant BEST has no defined result in the reference (MLLocation.cpp:379-383)");
+    }
+    /* getPose solves from the stored ranges and the fixed seed every time (:426-441): no extrapolation, no clock.
+     * Before the first ranging epoch the reference indexes an empty covariance; here getPose returns false. */
+    bool getPose(Vector3 &pose) override {
+        if (!started_) return false;
+        double pos[3], cov[9], vel[3];
+        uint32_t st = 0;
+        check(kfpos_get_pose(h_, 0.0, pos, cov, vel, &st));
+        if (st & KFPOS_ST_NOT_STARTED) return false;
+        pose = Vector3();
+        pose.x = pos[0]; pose.y = pos[1]; pose.z = pos[2];
+        pose.covarianceDim = 6; /* eye(6,6) * 0 with the 3x3 block, :449-464 */
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) pose.covarianceMatrix[i * 6 + j] = cov[3 * i + j];
+        return true;
+    }
+
+protected:
+    void fillPose(Vector3 &, const double *, const double *) override {}
 };
 
 /* ---- ALGORITHM_KF: the 8-state planar filter ---- */

@@ -44,6 +44,7 @@ struct NodeParams { /* names and defaults: node_pos.cpp:48-109, kfpos_toa.launch
     double heuristicIgnoreThreshold = 0.5;
     /* ALGORITHM_KF (node_pos.cpp:64-97): initAngle is only read with useStartPosition = 1; the use* switches decide
      * which topics are subscribed; config*: files behind the five XML parameters (<param textfile=.../>) */
+    int use2d = 0, variant = 0, numRangingsToIgnore = 0; /* ALGORITHM_ML, node_pos.cpp:79-81 */
     double initAngle = 0;
     int usePX4Flow = 0, useTOA = 1, useIMU = 0, useMAG = 0;
     std::string configPos, configPX4Flow, configUWB, configIMU, configMAG;
@@ -63,6 +64,9 @@ static bool set_param(NodeParams &p, const std::string &k, const std::string &v)
     else if (k == "initPositionZ") p.initPositionZ = atof(v.c_str());
     else if (k == "useHeuristicIgnoreWorst") p.useHeuristicIgnoreWorst = atoi(v.c_str());
     else if (k == "heuristicIgnoreThreshold") p.heuristicIgnoreThreshold = atof(v.c_str());
+    else if (k == "use2d") p.use2d = atoi(v.c_str());
+    else if (k == "variant") p.variant = atoi(v.c_str());
+    else if (k == "numRangingsToIgnore") p.numRangingsToIgnore = atoi(v.c_str());
     else if (k == "initAngle") p.initAngle = atof(v.c_str());
     else if (k == "usePX4Flow") p.usePX4Flow = atoi(v.c_str());
     else if (k == "useTOA") p.useTOA = atoi(v.c_str());
@@ -110,8 +114,13 @@ static std::unique_ptr<SingleTagFilter> make_algorithm(const NodeParams &p) {
                                             {"configMAG", p.configMAG}}));
         return std::unique_ptr<SingleTagFilter>(kf.release());
     }
-    throw std::invalid_argument("algorithm must be ALGORITHM_KF_TOA, ALGORITHM_KF_TOA_IMU or ALGORITHM_KF "
-                                "(single-tag ALGORITHM_ML: use the C ABI, KFPOS_MODEL_ML)");
+    if (p.algorithm == "ALGORITHM_ML") { /* Posgenerator.cpp:529-534 */
+        Vector3 seed;
+        seed.x = 1; seed.y = 1; seed.z = 4;
+        return std::unique_ptr<SingleTagFilter>(
+            new MLLocation(p.use2d != 0, p.variant, p.numRangingsToIgnore, p.useStartPosition ? init : seed));
+    }
+    throw std::invalid_argument("algorithm must be ALGORITHM_KF_TOA, ALGORITHM_KF_TOA_IMU, ALGORITHM_KF or ALGORITHM_ML");
 }
 
 /* The ranging epoch table of PosGenerator for one tag: ranges keyed by anchor column, flushed when a
