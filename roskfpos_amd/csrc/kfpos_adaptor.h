@@ -217,9 +217,11 @@ protected:
 };
 
 /* ---- ALGORITHM_ML: MLLocation as the estimator (MLLocation.cpp:421-486) ---- */
-#define ML_VARIANT_NORMAL 0   /* MLLocation.h:5-7 */
+#ifndef ML_VARIANT_NORMAL /* MLLocation.h:5-7; kept as macros so that node code using them compiles unchanged */
+#define ML_VARIANT_NORMAL 0
 #define ML_VARIANT_IGNORE_N 1
 #define ML_VARIANT_BEST 2
+#endif
 
 class MLLocation : public SingleTagFilter {
 public:
