@@ -36,6 +36,8 @@ CONFIGS = {
     # 8-state planar filter (KalmanFilter): ranging-only bank, and the same with IMU + compass samples latched
     # (every ranging epoch then carries 4 sensor rows; LDS-staged kernel). state 7+36 doubles r/w, epoch 96 B,
     # trajectory 24 B, flags + status 12 B
+    # standalone ML estimator (ALGORITHM_ML): position 3 + covariance 6 doubles written, epoch 96 B read
+    "ml": (2, 65536, 8, capi.STORE_F64, 0, False, 96 + 72 + 24),
     "planar": (3, 65536, 8, capi.STORE_F64, 0, False, 820),
     "planar_sens": (3, 65536, 8, capi.STORE_F64, 0, False, 820 + 80),
 }
@@ -80,12 +82,23 @@ def run(name, steps, warmup):
     ms = bank.timing_end(stream)
     us = ms * 1e3 / steps
     st = status.cpu().numpy().astype(np.uint32)
+    # getPose kernel (predict-only extrapolation of every tag), device buffers: state in, pos 3 + cov 9 + vel 3 out
+    pos_t = torch.zeros((3, T), dtype=torch.float64, device=dev)
+    cov_t = torch.zeros((9, T), dtype=torch.float64, device=dev)
+    vel_t = torch.zeros((3, T), dtype=torch.float64, device=dev)
+    for _ in range(3):
+        bank.get_pose_dev(0.02, pos_t, cov_t, vel_t, status, stream)
+    torch.cuda.synchronize()
+    bank.timing_begin(stream)
+    for _ in range(20):
+        bank.get_pose_dev(0.02, pos_t, cov_t, vel_t, status, stream)
+    pose_us = bank.timing_end(stream) * 1e3 / 20
     x, _, _ = bank.get_state()
     truth = w.position(w.time_of(S - 1))
     if model == 3:
         x, truth = x[:, :2], truth[:, :2]
     out = {"config": name, "tags": T, "anchors": A, "us_per_launch": round(us, 2),
-           "tag_steps_per_s": T / us * 1e6, "algo_GBps": nbytes * T / us / 1e3,
+           "tag_steps_per_s": T / us * 1e6, "get_pose_us": round(pose_us, 2), "algo_GBps": nbytes * T / us / 1e3,
            "hbm_frac": nbytes * T / us / 1e3 / 8000.0,
            "mean_gain_iters": float(((st >> 8) & 0xFF).mean()), "mean_ml_iters": float(((st >> 16) & 0xFF).mean()),
            "max_gain_iters": int(((st >> 8) & 0xFF).max()),
