@@ -9,8 +9,8 @@
  *   KalmanFilter                  src/kfpos/algorithms/KalmanFilter.h:29-133 (8-state planar filter, ALGORITHM_KF)
  *   MLLocation                    src/kfpos/algorithms/MLLocation.h:26-70 as an estimator (ALGORITHM_ML; 3-D, variants 0 and 1)
  *   Vector3 / VectorDim3 / Beacon src/kfpos/algorithms/sensor_types.h:7-25
- * Differences, all at the type level: Vector3::covarianceMatrix is a plain row-major array with its
- * dimension (the reference embeds an arma::mat); the estimator reads time from an injectable clock
+ * Differences, all at the type level: Vector3::covarianceMatrix is a fixed-capacity matrix with the arma::mat
+ * accessors the node uses (the reference embeds an arma::mat); the estimator reads time from an injectable clock
  * (default std::chrono::steady_clock, as KalmanFilterTOA.cpp:76-88 does) so tests can replay traces.
  *
  * Each object is ONE filter (n_tags = 1), which is what the reference node runs; batched callers use
@@ -37,13 +37,50 @@
 
 namespace kfpos_host {
 
-struct Vector3 { /* sensor_types.h:7-13 */
-    double x = 0, y = 0, z = 0;
-    double rotX = 0, rotY = 0, rotZ = 0, rotW = 0;
-    double linearSpeedX = 0, linearSpeedY = 0, linearSpeedZ = 0;
-    double angularSpeedX = 0, angularSpeedY = 0, angularSpeedZ = 0;
-    int covarianceDim = 0;             /* 6 (TOA, planar) or 9 (TOA+IMU): stateToPose */
-    double covarianceMatrix[81] = {0}; /* row-major covarianceDim x covarianceDim */
+/* The slice of arma::mat that code holding a Vector3 uses on covarianceMatrix (sensor_types.h:12): element access
+ * (i, j), Armadillo's column-major LINEAR access (i) -- how publishPositionReport copies the first 36 elements
+ * into the ROS messages, Posgenerator.cpp:397-399, 448-449 --, n_rows / n_cols / n_elem, zeros() / eye(). Fixed
+ * capacity 9 x 9 (the largest stateToPose fills, KalmanFilterTOAIMU.cpp:217), no heap. Out-of-range access throws
+ * std::logic_error, as Armadillo's default bounds check does. */
+struct CovarianceMatrix {
+    int n_rows, n_cols, n_elem;
+    double mem[81]; /* column-major, like arma::mat::mem */
+    CovarianceMatrix() : n_rows(0), n_cols(0), n_elem(0) { std::memset(mem, 0, sizeof(mem)); }
+    CovarianceMatrix(int rows, int cols) { zeros(rows, cols); }
+    void zeros(int rows, int cols) {
+        if (rows < 0 || cols < 0 || rows * cols > 81) throw std::logic_error("CovarianceMatrix: at most 81 elements");
+        n_rows = rows; n_cols = cols; n_elem = rows * cols;
+        std::memset(mem, 0, sizeof(mem));
+    }
+    void eye(int rows, int cols, double scale = 1.0) { /* arma::eye<arma::mat>(rows, cols) * scale */
+        zeros(rows, cols);
+        for (int i = 0; i < rows && i < cols; ++i) mem[i * rows + i] = scale;
+    }
+    double &operator()(int i) { return mem[lin(i)]; }
+    const double &operator()(int i) const { return mem[lin(i)]; }
+    double &operator()(int r, int c) { return mem[at(r, c)]; }
+    const double &operator()(int r, int c) const { return mem[at(r, c)]; }
+
+private:
+    int lin(int i) const {
+        if (i < 0 || i >= n_elem) throw std::logic_error("Mat::operator(): index out of bounds");
+        return i;
+    }
+    int at(int r, int c) const {
+        if (r < 0 || c < 0 || r >= n_rows || c >= n_cols) throw std::logic_error("Mat::operator(): index out of bounds");
+        return c * n_rows + r;
+    }
+};
+
+/* sensor_types.h:7-13. An aggregate with the reference's member order and no default member initialisers, so that
+ * `Vector3 pose = {NAN, NAN, NAN};` (Posgenerator.cpp:542) is aggregate initialisation under the reference's
+ * -std=c++11 (CMakeLists.txt:7-9): the members not named are value-initialised (0, empty matrix). */
+struct Vector3 {
+    double x, y, z;
+    double rotX, rotY, rotZ, rotW;
+    double linearSpeedX, linearSpeedY, linearSpeedZ;
+    double angularSpeedX, angularSpeedY, angularSpeedZ;
+    CovarianceMatrix covarianceMatrix;
 };
 struct VectorDim3 { double x, y, z; };  /* sensor_types.h:15-17 */
 struct Beacon {                          /* sensor_types.h:19-23 */
@@ -173,9 +210,9 @@ protected:
     void fillPose(Vector3 &pose, const double *x, const double *P) override {
         pose = Vector3(); /* stateToPose, KalmanFilterTOA.cpp:159-183: zero quaternion, 6x6 with the position block */
         pose.x = x[0]; pose.y = x[1]; pose.z = x[2];
-        pose.covarianceDim = 6;
+        pose.covarianceMatrix.zeros(6, 6);
         for (int i = 0; i < 3; ++i)
-            for (int j = 0; j < 3; ++j) pose.covarianceMatrix[i * 6 + j] = P[i * 6 + j];
+            for (int j = 0; j < 3; ++j) pose.covarianceMatrix(i, j) = P[i * 6 + j];
     }
 };
 
@@ -204,15 +241,14 @@ protected:
         /* sic: the acceleration state is reported in the angularSpeed fields (:213-215); it is never
          * persisted, so the predicted value is 0 */
         pose.angularSpeedX = x[6]; pose.angularSpeedY = x[7]; pose.angularSpeedZ = x[8];
-        pose.covarianceDim = 9;
-        for (int i = 0; i < 9; ++i) pose.covarianceMatrix[i * 9 + i] = 0.01; /* eye(9,9) * 0.01, :217 */
+        pose.covarianceMatrix.eye(9, 9, 0.01); /* eye(9,9) * 0.01, :217 */
         for (int i = 0; i < 3; ++i)
-            for (int j = 0; j < 3; ++j) pose.covarianceMatrix[i * 9 + j] = P[i * 9 + j];
+            for (int j = 0; j < 3; ++j) pose.covarianceMatrix(i, j) = P[i * 9 + j];
         for (int i = 0; i < 3; ++i) { /* sic: row/column 7 receive P(.,8) (:231-239) */
-            pose.covarianceMatrix[i * 9 + 7] = P[i * 9 + 8];
-            pose.covarianceMatrix[7 * 9 + i] = P[8 * 9 + i];
+            pose.covarianceMatrix(i, 7) = P[i * 9 + 8];
+            pose.covarianceMatrix(7, i) = P[8 * 9 + i];
         }
-        pose.covarianceMatrix[7 * 9 + 7] = P[8 * 9 + 8];
+        pose.covarianceMatrix(7, 7) = P[8 * 9 + 8];
     }
 };
 
@@ -247,9 +283,9 @@ public:
         if (st & KFPOS_ST_NOT_STARTED) return false;
         pose = Vector3();
         pose.x = pos[0]; pose.y = pos[1]; pose.z = pos[2];
-        pose.covarianceDim = 6; /* eye(6,6) * 0 with the 3x3 block, :449-464 */
+        pose.covarianceMatrix.zeros(6, 6); /* eye(6,6) * 0 with the 3x3 block, :449-464 */
         for (int i = 0; i < 3; ++i)
-            for (int j = 0; j < 3; ++j) pose.covarianceMatrix[i * 6 + j] = cov[3 * i + j];
+            for (int j = 0; j < 3; ++j) pose.covarianceMatrix(i, j) = cov[3 * i + j];
         return true;
     }
 
@@ -435,17 +471,16 @@ protected:
         pose.rotW = std::cos(half);
         pose.linearSpeedX = x[2]; pose.linearSpeedY = x[3];
         pose.angularSpeedZ = x[7];
-        pose.covarianceDim = 6;
-        for (int i = 0; i < 6; ++i) pose.covarianceMatrix[i * 6 + i] = 0.01;
-        pose.covarianceMatrix[0 * 6 + 0] = P[0 * 8 + 0];
-        pose.covarianceMatrix[0 * 6 + 1] = P[0 * 8 + 1];
-        pose.covarianceMatrix[1 * 6 + 0] = P[1 * 8 + 0];
-        pose.covarianceMatrix[1 * 6 + 1] = P[1 * 8 + 1];
-        pose.covarianceMatrix[0 * 6 + 5] = P[0 * 8 + 6];
-        pose.covarianceMatrix[1 * 6 + 5] = P[1 * 8 + 6];
-        pose.covarianceMatrix[5 * 6 + 0] = P[6 * 8 + 0];
-        pose.covarianceMatrix[5 * 6 + 1] = P[6 * 8 + 1];
-        pose.covarianceMatrix[5 * 6 + 5] = P[6 * 8 + 6];
+        pose.covarianceMatrix.eye(6, 6, 0.01);
+        pose.covarianceMatrix(0, 0) = P[0 * 8 + 0];
+        pose.covarianceMatrix(0, 1) = P[0 * 8 + 1];
+        pose.covarianceMatrix(1, 0) = P[1 * 8 + 0];
+        pose.covarianceMatrix(1, 1) = P[1 * 8 + 1];
+        pose.covarianceMatrix(0, 5) = P[0 * 8 + 6];
+        pose.covarianceMatrix(1, 5) = P[1 * 8 + 6];
+        pose.covarianceMatrix(5, 0) = P[6 * 8 + 0];
+        pose.covarianceMatrix(5, 1) = P[6 * 8 + 1];
+        pose.covarianceMatrix(5, 5) = P[6 * 8 + 6];
     }
 
 private:

@@ -78,11 +78,7 @@ public:
         if (std::isnan(report.x)) return false; /* :387 */
         const PoseMsg p = {report.x, report.y, report.z, report.rotX, report.rotY, report.rotZ, report.rotW};
         double lin[36];
-        const int d = report.covarianceDim > 0 ? report.covarianceDim : 6;
-        for (int i = 0; i < 36; ++i) { /* covarianceMatrix(i): column-major linear index */
-            const int r = i % d, c = i / d;
-            lin[i] = report.covarianceMatrix[r * d + c];
-        }
+        for (int i = 0; i < 36; ++i) lin[i] = report.covarianceMatrix(i); /* column-major linear index, :397-399 */
         msg.frame_id = "world";
         msg.stamp = now;
         msg.pose = p;
@@ -116,8 +112,7 @@ public:
 
     /* publishFixedRateReport: pose = {NaN, NaN, NaN}; getPose; publish if it returned true */
     bool fixedRateReport(PositionEstimationAlgorithm &alg, double now) {
-        Vector3 pose;
-        pose.x = pose.y = pose.z = NAN;
+        Vector3 pose = {NAN, NAN, NAN}; /* Posgenerator.cpp:542 */
         if (!alg.getPose(pose)) return false;
         return publish(pose, now);
     }

@@ -87,7 +87,7 @@ static bool set_param(NodeParams &p, const std::string &k, const std::string &v)
 
 /* PosGenerator::setAlgorithm, Posgenerator.cpp:510-538 */
 static std::unique_ptr<SingleTagFilter> make_algorithm(const NodeParams &p) {
-    Vector3 init;
+    Vector3 init = Vector3();
     init.x = p.initPositionX; init.y = p.initPositionY; init.z = p.initPositionZ;
     if (p.algorithm == "ALGORITHM_KF_TOA") {
         /* sic: the reference's branch is inverted here (Posgenerator.cpp:512-516): WITHOUT
@@ -115,7 +115,7 @@ static std::unique_ptr<SingleTagFilter> make_algorithm(const NodeParams &p) {
         return std::unique_ptr<SingleTagFilter>(kf.release());
     }
     if (p.algorithm == "ALGORITHM_ML") { /* Posgenerator.cpp:529-534 */
-        Vector3 seed;
+        Vector3 seed = Vector3();
         seed.x = 1; seed.y = 1; seed.z = 4;
         return std::unique_ptr<SingleTagFilter>(
             new MLLocation(p.use2d != 0, p.variant, p.numRangingsToIgnore, p.useStartPosition ? init : seed));
@@ -134,7 +134,7 @@ struct EpochAssembler {
 
     void addAnchor(int id, double x, double y, double z) {
         if (column.count(id)) return;
-        Beacon b;
+        Beacon b = Beacon();
         b.id = id;
         b.index = (int)beacons.size();
         b.position.x = x; b.position.y = y; b.position.z = z;
@@ -388,12 +388,12 @@ int main(int argc, char **argv) {
                 printf("\n");
             } else if (kind == 'P') {
                 ss >> now;
-                Vector3 pose;
-                pose.x = pose.y = pose.z = NAN;
+                Vector3 pose = {NAN, NAN, NAN};
                 const bool ok = alg->getPose(pose);
-                const int d = pose.covarianceDim ? pose.covarianceDim : 6;
+                const bool filled = pose.covarianceMatrix.n_rows >= 3;
                 printf("P %.9f %d %.17g %.17g %.17g %.17g %.17g %.17g\n", now, ok ? 1 : 0, pose.x, pose.y, pose.z,
-                       pose.covarianceMatrix[0], pose.covarianceMatrix[d + 1], pose.covarianceMatrix[2 * d + 2]);
+                       filled ? pose.covarianceMatrix(0, 0) : 0.0, filled ? pose.covarianceMatrix(1, 1) : 0.0,
+                       filled ? pose.covarianceMatrix(2, 2) : 0.0);
             }
         }
     } catch (const std::exception &e) {
