@@ -1,14 +1,21 @@
 #!/usr/bin/env python3
 """bench.py -- EKF predict+update throughput of the MI355X batched core on BASELINE.json's metric.
 
-Workload (BASELINE.json configs[2], the configuration the metric is quoted on): 65 536 tags x 8 anchors
-PER GPU, UWB+IMU fused 9-state EKF (kfpos_toa_imu path), fp64 arithmetic, synthetic traces of SURVEY.md
-8d. One "step" = one ranging epoch for every tag: predict + full iterated update fusing the epoch's
-accelerometer sample, and the resulting pose written out. All inputs for every step are resident in HBM
-before the timed region. The trace is replayed with kfpos_run_trace_dev: --epochs-per-launch epochs per
-kernel launch (the per-tag state stays in registers between them; 1 = one launch per epoch, which is also
-measured and reported as `per_epoch_launch`). With --gpus N > 1 (weak scaling: every rank owns 65 536 tags)
-the poses at the end of every launch are all-gathered over RCCL, overlapped with the next launch.
+Default workload (--config c3 = BASELINE.json configs[2], the configuration the metric is quoted on): 65 536 tags x
+8 anchors PER GPU (weak scaling), UWB+IMU fused 9-state IEKF (kfpos_toa_imu path), fp64 arithmetic, synthetic traces
+of SURVEY.md 8d. One "step" = one ranging epoch for every tag: predict + full iterated update fusing the epoch's
+accelerometer sample, and the resulting pose written out. All inputs for every step are resident in HBM before the
+timed region. The trace is replayed with kfpos_run_trace_dev: --epochs-per-launch epochs per kernel launch (the
+per-tag state stays in registers between them). The same K epochs are also replayed with ONE launch (and, with several
+ranks, one pose all-gather) per epoch -- what a live 20 Hz node pays -- and reported as `per_epoch_launch`.
+
+--config c4 = BASELINE.json configs[3]: 1 048 576 tags x 8 anchors in total, UWB-only 6-state EKF, f64, the tag batch
+split over the ranks by dist.shard_range (strong scaling: the total is fixed), poses exchanged with one RCCL all-gather
+per launch (--gather launch, the default), per epoch (--gather epoch) or per launch with every epoch's poses
+(--gather trajectory).
+
+With --gpus N > 1 rank g owns the contiguous global tag range shard_range(total, N, g) and regenerates exactly its
+own inputs; the pose all-gather runs on a side stream, overlapped with the next launch (roskfpos_amd/dist.py).
 
 Prints ONE JSON line on rank 0 (contract in the task description), with `roofline` for the step kernel
 and `cpu_baseline` = the oracle timed on the host cores over a bounded sample of the same workload.
@@ -27,65 +34,101 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from roskfpos_amd import capi  # noqa: E402
-from roskfpos_amd.dist import PoseGather, env_world, shard_range  # noqa: E402
+from roskfpos_amd.dist import GATHER_MODES, ShardedReplay, device_trace, env_world, shard_range  # noqa: E402
 from roskfpos_amd.synth import Workload  # noqa: E402
 
-TAGS_PER_GPU = 65536
 ANCHORS = 8
-# algorithmic bytes per tag-step of config 3 -- read x(9) + packed P(45) as f32, write them
-# back, 8 int32 ranges + 8 f32 errorEstimations, accel(3) + covariance(9) f32:
-#   (9+45)*4*2 + 8*4*2 + (3+9)*4 = 544 B
-ALGO_BYTES_PER_TAG_STEP = 544
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-# Covariance storage in HBM. BASELINE configs[2] says fp32, but with a 24-bit covariance the 9-state filter
-# sits at 1.6e-6 m RMS from the CPU reference over 100 steps (tests/test_gpu_parity.py), above the 1e-6 m
-# bar, so the measured configuration keeps it in f64 (KFPOS_STORE_MIXED: measurements stay f32 / int32). The kernel is
-# VALU-bound, so this does not change its duration; DESIGN.md "storage precision".
-STORAGE = {"mixed": capi.STORE_MIXED, "f64": capi.STORE_F64, "f32": capi.STORE_F32}[
+
+# SURVEY.md 8d, algorithmic bytes per tag-step:
+#   c3: read x(9) + packed P(45) as f32, write them back, 8 int32 ranges + 8 f32 errorEstimations,
+#       accel(3) + covariance(9) f32:                          (9+45)*4*2 + 8*4*2 + (3+9)*4 = 544 B
+#   c4 / 6-state f64: x(6) + packed P(21) f64 in and out, 8 ranges + 8 errorEstimations at 8 B:
+#                                                              (6+21)*8*2 + 8*8*2           = 560 B
+# Covariance storage of c3: BASELINE configs[2] says fp32, but with a 24-bit covariance the 9-state filter sits at
+# 1.6e-6 m RMS from the CPU reference over 100 steps (tests/test_gpu_parity.py), above the 1e-6 m bar, so the measured
+# configuration keeps it in f64 (KFPOS_STORE_MIXED: measurements stay f32 / int32). The kernel is VALU-bound, so this
+# does not change its duration; DESIGN.md "storage precision".
+STORAGE_C3 = {"mixed": capi.STORE_MIXED, "f64": capi.STORE_F64, "f32": capi.STORE_F32}[
     os.environ.get("KFPOS_BENCH_STORAGE", "mixed")]
+CONFIGS = {
+    "c3": dict(model=capi.MODEL_TOA_IMU, storage=STORAGE_C3, bytes=544, scaling="weak", tags=65536,
+               kernel="k_step_imu9<double,float,8>", dtype="f64 arithmetic; f64 state and covariance, f32/int32 "
+               "measurements in HBM (KFPOS_STORE_MIXED)",
+               workload="BASELINE configs[2]: 65536 tags x 8 anchors per GPU, UWB+IMU fused 9-state IEKF "
+                        "(kfpos_toa_imu path), fp64 arithmetic, f32/int32 measurements, f64 covariance "
+                        "(KFPOS_STORE_MIXED: a 24-bit covariance misses the 1e-6 m bar)"),
+    "c4": dict(model=capi.MODEL_TOA, storage=capi.STORE_F64, bytes=560, scaling="strong", tags=1048576,
+               kernel="k_step_toa6<true,double,double,8,0>", dtype="f64",
+               workload="BASELINE configs[3]: 1048576 tags x 8 anchors in total, UWB-only 6-state IEKF, f64, "
+                        "sharded over the ranks (dist.shard_range), pose all-gather"),
+}
 
 
-def upload_trace(torch, w, n_steps, device):
-    """ranges [S][A][T] int32, accel [S][3][T] f32, err [A][T] f32, cov [9][T] f32, dt (S,)"""
-    T, A = w.n_tags, w.n_anchors
-    ranges = torch.empty((n_steps, A, T), dtype=torch.int32, device=device)
-    accel = torch.empty((n_steps, 3, T), dtype=torch.float32, device=device)
-    dts = np.zeros(n_steps)
-    for s in range(n_steps):
-        ranges[s].copy_(torch.from_numpy(np.ascontiguousarray(w.ranges_mm(s).T)))
-        accel[s].copy_(torch.from_numpy(np.ascontiguousarray(w.accel(s, np.float32).T)))
-        dts[s] = w.dt_of(s)
-    err = torch.from_numpy(np.ascontiguousarray(w.err_est(np.float32).T)).to(device)
-    cov = torch.from_numpy(np.ascontiguousarray(w.accel_cov(np.float32).T)).to(device)
-    return ranges, accel, err, cov, dts
-
-
-def cpu_baseline_and_rms(w, anchors, sample_tags, sample_steps, threads):
+def cpu_baseline_and_rms(cfg, w, sample_tags, sample_steps, threads):
     """Oracle (the CPU restatement of the reference path) on a bounded sample of the same workload,
     and the GPU's RMS position difference against it on that sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py
+    imu = cfg["model"] == capi.MODEL_TOA_IMU
+    real = np.float64 if cfg["storage"] == capi.STORE_F64 else np.float32
     ws = Workload(sample_tags, ANCHORS, tag0=w.tag0)
-    e32 = ws.err_est(np.float32)
-    c32 = ws.accel_cov(np.float32)
-    e64, c64 = e32.astype(np.float64), c32.astype(np.float64)
-    orc = oracle_py.OracleBank(1, sample_tags, anchors, init_pos=ws.init_positions(), n_threads=threads)
-    gpu = capi.KfposBank(capi.MODEL_TOA_IMU, sample_tags, anchors, storage=STORAGE,
-                         init_pos=ws.init_positions())
+    er = ws.err_est(real)
+    e64 = er.astype(np.float64)
+    orc = oracle_py.OracleBank(cfg["model"], sample_tags, ws.anchors, init_pos=ws.init_positions(), n_threads=threads)
+    gpu = capi.KfposBank(cfg["model"], sample_tags, ws.anchors, storage=cfg["storage"], init_pos=ws.init_positions())
+    if imu:
+        cr = ws.accel_cov(real)
+        c64 = cr.astype(np.float64)
     cpu_s = 0.0
     for s in range(sample_steps):
-        r, a32, dt = ws.ranges_mm(s), ws.accel(s, np.float32), ws.dt_of(s)
-        a64 = a32.astype(np.float64)
-        t0 = time.perf_counter()
-        orc.step_imu(a64, c64, 0.0)   # newIMUMeasurement at timeLag 0 (latch), then the ranging epoch
-        orc.step_toa(r, e64, dt)
-        cpu_s += time.perf_counter() - t0
-        gpu.step_toa_imu(r, e32, a32, c32, dt)
+        r, dt = ws.ranges_mm(s), ws.dt_of(s)
+        if imu:
+            ar = ws.accel(s, real)
+            a64 = ar.astype(np.float64)
+            t0 = time.perf_counter()
+            orc.step_imu(a64, c64, 0.0)   # newIMUMeasurement at timeLag 0 (latch), then the ranging epoch
+            orc.step_toa(r, e64, dt)
+            cpu_s += time.perf_counter() - t0
+            gpu.step_toa_imu(r, er, ar, cr, dt)
+        else:
+            t0 = time.perf_counter()
+            orc.step_toa(r, e64, dt)
+            cpu_s += time.perf_counter() - t0
+            gpu.step_toa(r, er, dt)
     xo, _ = orc.get_state()
     xg, _, _ = gpu.get_state()
     gpu.close()
     rms = float(np.sqrt(((xo[:, :3] - xg[:, :3]) ** 2).sum(1).mean()))
     return sample_tags * sample_steps / cpu_s, cpu_s, rms
+
+
+def static_counters(kernel_key, epochs_in_launch):
+    """HBM traffic / VALU counters of the step kernel from the committed rocprofv3 --pmc summaries. They are NOT
+    measured by this run (PMC collection needs its own profiler passes, MI355X_MICROARCH.md): every entry carries its
+    source, and the byte count is rebuilt for the launch length actually timed from the two components the summaries
+    separate -- state traffic paid once per launch, measurement + pose traffic paid per epoch."""
+    out = {"traffic": None, "traffic_source": None, "valu": None}
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    try:
+        t = json.load(open(tpath)).get(kernel_key)
+        if t:
+            out["traffic"] = t["bytes_per_launch_fixed"] + t["bytes_per_epoch"] * epochs_in_launch
+            out["traffic_source"] = (f"profiles/traffic_latest.json (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                     f"passes of {t['measured_with']}; {t['bytes_per_launch_fixed']:.0f} B per launch + "
+                                     f"{t['bytes_per_epoch']:.0f} B per epoch, rebuilt for {epochs_in_launch:g} epochs)")
+    except Exception:
+        pass
+    ppath = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    try:
+        c = json.load(open(ppath)).get(kernel_key)
+        if c:
+            out["valu"] = {"busy_frac": c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"],
+                           "fp64_instr_per_wave_epoch": c["SQ_INSTS_VALU"] / c["SQ_WAVES"] / c["epochs_per_launch"],
+                           "source": f"profiles/pmc_latest.json (static: {c['measured_with']})"}
+    except Exception:
+        pass
+    return out
 
 
 def main():
@@ -94,12 +137,18 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50,
                     help="untimed epochs first; the chip needs a few launches to settle its clocks under this fp64 load")
-    ap.add_argument("--tags-per-gpu", type=int, default=TAGS_PER_GPU)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c3")
+    ap.add_argument("--tags-per-gpu", type=int, default=None, help="c3: tags per rank (default 65536)")
+    ap.add_argument("--total-tags", type=int, default=None, help="c4: tags in total (default 1048576)")
     ap.add_argument("--epochs-per-launch", type=int, default=25,
                     help="epochs fused into one kernel launch (state resident in registers); 1 = one launch per epoch")
+    ap.add_argument("--gather", choices=GATHER_MODES, default="launch",
+                    help="pose all-gather of the main measurement with several ranks (dist.ShardedReplay)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-per-epoch", action="store_true", help="skip the extra one-launch-per-epoch measurement")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the 6-state 65536 x 8 line of the c3 run")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
 
     import torch
     import torch.distributed as dist
@@ -121,18 +170,25 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    T = args.tags_per_gpu
     K, W = args.steps, args.warmup
     E = max(1, min(args.epochs_per_launch, 128))
-    lo, hi = shard_range(T * world, world, rank)
+    if cfg["scaling"] == "weak":
+        per_rank = args.tags_per_gpu or cfg["tags"]
+        total = per_rank * world
+    else:
+        total = args.total_tags or cfg["tags"]
+    lo, hi = shard_range(total, world, rank)
+    T = hi - lo
+    imu = cfg["model"] == capi.MODEL_TOA_IMU
+    real = np.float64 if cfg["storage"] == capi.STORE_F64 else np.float32
     w = Workload(T, ANCHORS, tag0=lo)
-    ranges, accel, err, cov, dts = upload_trace(torch, w, W + K, device)
+    trace = device_trace(torch, w, W + K, device, imu, real)
+    # every kfpos launch and every copy into the gather buffers goes to torch's current stream, so that the HIP
+    # events of kfpos_timing_* and torch's stream semantics see the same queue
     stream = torch.cuda.current_stream().cuda_stream
-    traj = torch.zeros((W + K, 3, T), dtype=torch.float64, device=device)  # pose after every epoch
 
-    def make_bank():
-        return capi.KfposBank(capi.MODEL_TOA_IMU, T, w.anchors, storage=STORAGE,
-                              init_pos=w.init_positions(), device=local_rank)
+    def make_bank(model=cfg["model"], storage=cfg["storage"]):
+        return capi.KfposBank(model, T, w.anchors, storage=storage, init_pos=w.init_positions(), device=local_rank)
 
     def fence():
         torch.cuda.synchronize()
@@ -140,36 +196,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(epochs_per_launch):
-        """W warm-up epochs, then exactly K timed epochs. Every launch covers `epochs_per_launch` epochs
-        (predict + update for every tag in each) and writes the pose after each epoch; with several
-        ranks the poses at the end of every launch are all-gathered over RCCL, overlapped with the next
-        launch. Returns (wall seconds, HIP-event ms around the step launches, number of launches, bank)."""
-        bank = make_bank()
-        gather = PoseGather(T, device) if world > 1 else None
-        launches = 0
-
-        def run(s0, n):
-            nonlocal launches
-            s = s0
-            while s < s0 + n:
-                m = min(epochs_per_launch, s0 + n - s)
-                bank.run_trace_dev(m, ranges[s], ANCHORS * T, err, 0, dts[s:s + m], accel=accel[s],
-                                   stride_accel=3 * T, cov=cov, stride_cov=0, trajectory=traj[s], stream=stream)
-                launches += 1
-                s += m
-                if gather is not None:
-                    gather.buffer().copy_(traj[s - 1], non_blocking=True)
-                    gather.gather()
-            if gather is not None:
-                gather.wait()
-
-        run(0, W)
+    def measure(epochs_per_launch, gather_mode, tr=trace, bank=None):
+        """W warm-up epochs, then exactly K timed epochs. Every launch covers `epochs_per_launch` epochs (predict +
+        update for every tag in each) and writes the pose after each epoch; with several ranks the poses are
+        all-gathered per `gather_mode`, overlapped with the next launch. Returns (wall seconds, HIP-event ms around
+        the timed launches, launches, gathers, bank)."""
+        bank = bank or make_bank()
+        rep = ShardedReplay(bank, total, device, gather_mode=gather_mode if world > 1 else "none",
+                            epochs_per_launch=epochs_per_launch, stream=stream)
+        rep.run(tr, 0, W)
         fence()
-        launches = 0
+        rep.launches = 0
+        g0 = rep.gather.count if rep.gather else 0
         bank.timing_begin(stream)
         t0 = time.perf_counter()
-        run(W, K)
+        rep.run(tr, W, K)
         kernel_ms = bank.timing_end(stream)  # HIP events on the launch stream around the timed launches
         fence()
         elapsed = time.perf_counter() - t0
@@ -177,79 +218,90 @@ def main():
             tmax = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=device)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed, kernel_ms = float(tmax[0]), float(tmax[1])
-        return elapsed, kernel_ms, launches, bank
+        return elapsed, kernel_ms, rep.launches, (rep.gather.count - g0 if rep.gather else 0), bank
 
-    elapsed, kernel_ms, launches, bank = measure(E)
+    # ---- secondary measurements first (they also bring the chip to its steady clocks under this fp64 load) ----
+    per_epoch = None
+    if not args.no_per_epoch and E != 1:
+        e1, k1, l1, g1, b1 = measure(1, "epoch")
+        b1.close()
+        per_epoch = {"value": total * K / e1, "unit": "tag-steps/s", "ms_per_step": e1 * 1e3 / K,
+                     "kernel_us_per_launch": k1 * 1e3 / l1, "launches": l1, "pose_gathers": g1,
+                     "algorithmic_GBps": cfg["bytes"] * T / (k1 * 1e-3 / l1) / 1e9,
+                     "what": "the same K epochs with ONE launch" + (" and one pose all-gather" if world > 1 else "") +
+                             " per epoch: the cost of a live 20 Hz caller of kfpos_step_*_dev"}
+    secondary = None
+    if args.config == "c3" and not args.no_secondary:
+        # the 6-state filter on the same ranging trace (kbench's toa6_65k): the kernel BASELINE's >= 40 % HBM target
+        # is reachable for; f64 storage, so its errorEstimations are f64
+        tr6 = {"ranges": trace["ranges"], "dts": trace["dts"], "traj": trace["traj"],
+               "err": torch.from_numpy(np.ascontiguousarray(w.err_est(np.float64).T)).to(device)}
+        e6, k6, l6, _, b6 = measure(E, "none", tr=tr6, bank=make_bank(capi.MODEL_TOA, capi.STORE_F64))
+        b6.close()
+        a6 = 560 * (T * K / l6) / (k6 * 1e-3 / l6) / 1e9
+        secondary = {"toa6_65k": {
+            "workload": f"{T} tags x 8 anchors per GPU, UWB-only 6-state IEKF, f64 (the per-GPU shard shape of "
+                        "BASELINE configs[1]/[3]), same ranging trace, same K timed epochs",
+            "value": total * K / e6, "unit": "tag-steps/s", "ms_per_step": e6 * 1e3 / K,
+            "roofline": {"bound": "hbm", "achieved": a6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": a6 / HBM_PEAK_GBS, "kernel": "k_step_toa6<true,double,double,8,0>",
+                         "kernel_us_per_launch": k6 * 1e3 / l6, "epochs_per_timed_launch": K / l6,
+                         "algorithmic_bytes_per_tag_step": 560}}}
+
+    # ---- the main measurement ----
+    elapsed, kernel_ms, launches, gathers, bank = measure(E, args.gather)
     x, P, _ = bank.get_state()
     truth = w.position(w.time_of(W + K - 1))
     track_rms = float(np.sqrt(((x[:, :3] - truth) ** 2).sum(1).mean()))
     finite = bool(np.isfinite(x).all() and np.isfinite(P).all())
-    traj_ok = bool(np.array_equal(traj[W + K - 1].cpu().numpy().T, x[:, :3]))
+    traj_ok = bool(np.array_equal(trace["traj"][W + K - 1].cpu().numpy().T, x[:, :3]))
     bank.close()
-    per_epoch = None
-    if not args.no_per_epoch and E != 1:
-        e1, k1, l1, b1 = measure(1)
-        b1.close()
-        per_epoch = {"value": T * world * K / e1, "unit": "tag-steps/s", "ms_per_step": e1 * 1e3 / K,
-                     "kernel_us_per_launch": k1 * 1e3 / l1,
-                     "algorithmic_GBps": ALGO_BYTES_PER_TAG_STEP * T / (k1 * 1e-3 / l1) / 1e9}
 
     if rank == 0:
-        total_steps = T * world * K
+        total_steps = total * K
         value = total_steps / elapsed
         per_launch_s = kernel_ms * 1e-3 / launches
-        units_per_launch = T * K / launches
-        achieved = ALGO_BYTES_PER_TAG_STEP * units_per_launch / per_launch_s / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        # what actually bounds the step kernel: fp64 VALU issue (committed PMC summary of this same command)
-        valu = None
-        ppath = os.path.join(ROOT, "profiles", "r01h_pmc_sq_counters.json")
-        if os.path.exists(ppath):
-            try:
-                c = next(v for k, v in json.load(open(ppath)).items() if "k_step_imu9" in k)
-                valu = {"busy_frac": c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"],
-                        "fp64_instr_per_wave_epoch": c["SQ_INSTS_VALU"] / c["SQ_WAVES"] / 25,
-                        "source": "profiles/r01h_pmc_sq_counters.json (rocprofv3 --pmc, 25 epochs per launch)"}
-            except Exception:
-                valu = None
+        epochs_in_launch = K / launches           # mean epochs per timed launch (K need not be a multiple of E)
+        units_per_launch = T * epochs_in_launch
+        achieved = cfg["bytes"] * units_per_launch / per_launch_s / 1e9
+        st = static_counters(cfg["kernel"], epochs_in_launch)
+        gather_txt = "none (single GPU)"
+        if world > 1:
+            gather_txt = (("rccl" if backend == "nccl" else backend + " (rehearsal)") +
+                          f" all_gather_into_tensor, mode '{args.gather}' ({gathers} collectives in the timed region), "
+                          "side stream, overlapped with the next launch")
         out = {
             "metric": "EKF predict+update steps/s at 65536 tags x 8 anchors; RMS pos err vs CPU ref",
             "value": value, "unit": "tag-steps/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: 65536 tags x 8 anchors per GPU, UWB+IMU fused 9-state "
-                                   "IEKF (kfpos_toa_imu path), fp64 arithmetic, f32/int32 measurements, f64 "
-                                   "covariance (KFPOS_STORE_MIXED: a 24-bit covariance misses the 1e-6 m bar)",
-                       "tags_per_gpu": T, "anchors": ANCHORS, "total_tags": T * world,
-                       "epochs_per_launch": E, "pose_output": "every epoch ([S][3][T] f64)",
-                       "pose_gather": (("rccl" if backend == "nccl" else backend + " (rehearsal)") +
-                                       " all_gather per launch, overlapped") if world > 1 else "none (single GPU)"},
+            "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True, "scaling": cfg["scaling"],
+            "vs_baseline": None, "dtype": cfg["dtype"], "data": "synthetic",
+            "config": {"workload": cfg["workload"], "tags_per_gpu": T, "anchors": ANCHORS, "total_tags": total,
+                       "epochs_per_launch": E, "epochs_in_timed_launches": [min(E, K - s) for s in range(0, K, E)],
+                       "pose_output": "every epoch ([S][3][T] f64)", "pose_gather": gather_txt},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_step_imu9<double,float,8>", "kernel_us_per_launch": per_launch_s * 1e6,
-                         "units_per_launch": units_per_launch,
-                         "algorithmic_bytes_per_tag_step": ALGO_BYTES_PER_TAG_STEP,
-                         "valu": valu},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": st["traffic"],
+                         "traffic_source": st["traffic_source"],
+                         "kernel": cfg["kernel"], "kernel_us_per_launch": per_launch_s * 1e6,
+                         "epochs_per_timed_launch": epochs_in_launch, "units_per_launch": units_per_launch,
+                         "algorithmic_bytes_per_tag_step": cfg["bytes"],
+                         "algorithmic_bytes_per_launch": cfg["bytes"] * units_per_launch,
+                         "valu": st["valu"]},
             "state_finite": finite, "trajectory_matches_state": traj_ok, "rms_vs_truth_m": track_rms,
         }
         if per_epoch is not None:
             out["per_epoch_launch"] = per_epoch
+        if secondary is not None:
+            out["secondary"] = secondary
         if world == 1 and not args.no_cpu_baseline:
             threads = min(os.cpu_count() or 1, 16)
-            sample_tags, sample_steps = 16384, 220  # ~10 s of oracle time on 16 host threads
-            v, secs, rms = cpu_baseline_and_rms(w, w.anchors, sample_tags, sample_steps, threads)
-            v1, secs1, _ = cpu_baseline_and_rms(w, w.anchors, 1024, 60, 1)  # a 1-core figure beside it
+            sample_tags, sample_steps = (16384, 220) if imu else (32768, 400)  # ~10 s of oracle time on 16 threads
+            v, secs, rms = cpu_baseline_and_rms(cfg, w, sample_tags, sample_steps, threads)
+            v1, secs1, _ = cpu_baseline_and_rms(cfg, w, 1024, 60 if imu else 200, 1)  # a 1-core figure
             out["cpu_baseline"] = {"value": v, "unit": "tag-steps/s", "cores": threads, "kind": "port",
                                    "sample": f"first {sample_tags} tags x {sample_steps} steps of the same "
                                              f"workload ({secs:.1f} s of oracle time)",
                                    "one_core_value": v1,
-                                   "one_core_sample": f"first 1024 tags x 60 steps ({secs1:.1f} s)"}
+                                   "one_core_sample": f"first 1024 tags x {60 if imu else 200} steps ({secs1:.1f} s)"}
             out["rms_pos_err_vs_cpu_ref_m"] = rms
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -17,6 +17,17 @@
 
 using namespace kfpos;
 
+/* -DKFE_MSAN (tests/emu/msan_audit.sh, clang -fsanitize=memory): everything the GPU kernels leave undefined is
+ * poisoned here too -- the working-weight row of the epoch scratch (stage_epoch_lds* never writes it) and the
+ * errorEstimation of an absent range (whatever the caller left there) -- so that a read-before-write in the kernel
+ * body shows up as a MemorySanitizer report instead of as a run-to-run varying result on the GPU. */
+#ifdef KFE_MSAN
+#include <sanitizer/msan_interface.h>
+#define KFE_POISON(ptr, bytes) __msan_poison((ptr), (bytes))
+#else
+#define KFE_POISON(ptr, bytes) ((void)0)
+#endif
+
 /* the instantiation the library would launch: without an outlier heuristic the HEUR = false build of the step */
 template <bool SYMM, class SC>
 static uint32_t toa6_step(Tag6<SYMM> &tg, SC &sc, const Params &pr, double lag, double *park = nullptr, int stride = 0) {
@@ -129,6 +140,7 @@ static void fill_scratch(const kfe_bank *b, const int32_t *mm, const double *err
         sc.r[a] = mm[a] > 0 ? (double)mm[a] / 1000 : 0.0; /* Posgenerator.cpp:483-484 */
         sc.e[a] = err[a];
     }
+    KFE_POISON(sc.w, sizeof(double) * A);
 }
 
 } // extern "C"

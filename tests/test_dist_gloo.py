@@ -1,4 +1,4 @@
-"""N>1 path on CPU: tag sharding + per-epoch pose all-gather, world_size 2, gloo backend.
+"""N>1 path on CPU: tag sharding + per-epoch pose all-gather, world_size 2 (and 3), gloo backend.
 
 The compute on each rank is the host emulation of the kernel body (no GPU here); what is under test is
 roskfpos_amd.dist -- shard ranges, per-shard regeneration of the synthetic inputs, the double-buffered
@@ -15,10 +15,10 @@ import torch.multiprocessing as mp
 
 from cases import Case
 from impls import EmuImpl
-from roskfpos_amd.dist import PoseGather, shard_range
+from roskfpos_amd.dist import PoseGather, shard_range, shard_sizes
 from roskfpos_amd.synth import Workload
 
-T_TOTAL, A, S = 96, 8, 12
+T_TOTAL, A, S = 97, 8, 12  # 97: the two shards differ by one tag (49 + 48), the gather pads and trims
 
 
 def test_shard_ranges_cover_the_batch():
@@ -46,33 +46,46 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     lo, hi = shard_range(T_TOTAL, world, rank)
     poses = _run_shard(lo, hi - lo, S)
-    g = PoseGather(hi - lo, "cpu")
+    g = PoseGather(hi - lo, "cpu", sizes=shard_sizes(T_TOTAL, world))
+    assert g.uniform == (T_TOTAL % world == 0) and g.t_pad == -(-T_TOTAL // world)
     gathered = []
     for s in range(S):
         buf = g.buffer()
-        buf.copy_(torch.from_numpy(np.ascontiguousarray(poses[s].T)))  # component-major [3][T_local]
+        buf[:, :hi - lo].copy_(torch.from_numpy(np.ascontiguousarray(poses[s].T)))  # component-major [3][T_local]
         full = g.gather()
         g.wait()
-        gathered.append(full.clone().numpy())
+        gathered.append(g.assemble(full).clone().numpy())   # [3][T_TOTAL], padding dropped
+    # one collective carrying a whole block of epochs ("trajectory" mode of ShardedReplay)
+    gt = PoseGather(hi - lo, "cpu", rows=3 * S, sizes=shard_sizes(T_TOTAL, world))
+    gt.buffer()[:, :hi - lo].copy_(torch.from_numpy(np.concatenate([p.T for p in poses])))
+    block = gt.assemble(gt.gather()).clone().numpy()          # [3 S][T_TOTAL]
+    gt.wait()
     if rank == 0:
-        q.put(np.stack(gathered))  # [S][world][3][T_local]
+        q.put((np.stack(gathered), block))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_gather_equals_single_shard():
+@pytest.mark.parametrize("world", [2, 3])
+def test_gather_of_unequal_shards_equals_single_shard(world):
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = q.get(timeout=120)
+    got, block = q.get(timeout=180)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     single = np.stack(_run_shard(0, T_TOTAL, S))                      # [S][T][3]
-    merged = np.concatenate([got[:, r].transpose(0, 2, 1) for r in range(2)], axis=1)
-    assert np.array_equal(merged, single)                              # bit-for-bit
+    assert got.shape == (S, 3, T_TOTAL)
+    assert np.array_equal(got.transpose(0, 2, 1), single)              # bit-for-bit
+    assert np.array_equal(block.reshape(S, 3, T_TOTAL), got)
+
+
+def test_pose_gather_rejects_wrong_sizes():
+    with pytest.raises(ValueError):
+        PoseGather(10, "cpu", sizes=[11])
