@@ -920,10 +920,16 @@ void fill_args(const kfpos_handle *h, KArgs &a) {
 typedef void (*step_kernel_t)(const KArgs);
 
 /* Anchor-count specialisation. 8 anchors (BASELINE configs 2-4): epoch in registers (RegScratch), returns 8. 16 anchors
- * (config 5, 6-state): a register-resident epoch costs 96 more live registers and spills (measured: no faster than
- * the run-time loop, and on partially filled wavefronts the spilled build returned wrong, run-to-run varying
- * positions -- no kernel in this library may use scratch, checked at build time), so the epoch stays in LDS and only
- * the anchor loops are compile-time, in groups of 8 (StaticScratch): returns -16. Everything else: 0, the run-time loop. */
+ * (config 5, 6-state): a register-resident epoch costs 96 more live registers and spills to scratch, which is no faster
+ * than the run-time loop (measured in round 1), so the epoch stays in LDS and only the anchor loops are compile-time, in
+ * groups of 8 (StaticScratch): returns -16. Everything else: 0, the run-time loop.
+ * "No scratch" is a PERFORMANCE rule of this library (checked at build time), not a correctness crutch: round 1 saw
+ * wrong, run-to-run varying positions from a work-in-progress build of the spilling 16-anchor kernel and dropped it
+ * without a diagnosis. Round 2 could not reproduce that with the committed sources of either round -- the library as it
+ * stood before that commit and today's kernels with the register-resident 16-anchor instantiations re-enabled
+ * (236-960 bytes/lane of scratch) match the oracle and repeat bit for bit on full, partially filled and
+ * skipped-lane wavefronts (tools/exp/, profiles/r02b_*) -- and a MemorySanitizer build of the kernel body with every
+ * undefined input poisoned is clean (tests/emu/msan_audit.sh). DESIGN.md section 2. */
 int static_anchors(const kfpos_handle *h) {
     if (h->cfg.max_anchors == 8) return 8;
     /* 16 anchors (BASELINE config 5): compile-time loops over an LDS-resident epoch (StaticScratch), 6-state only */
