@@ -17,6 +17,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <string>
 #include <vector>
 
 struct kfe_bank;
@@ -102,7 +103,16 @@ static int run_case(const char *name, int model, int A, int use_static, int igno
     return 0;
 }
 
-int main() {
+int main(int argc, char **argv) {
+    if (argc > 1 && std::string(argv[1]) == "--selftest") {
+        /* the sanitizer must abort here: a branch on a poisoned value (proves the audit can see what it looks for) */
+        volatile double v = 1.0;
+        double w = v;
+        __msan_poison(&w, sizeof(w));
+        if (w > 0.5) std::printf("selftest: branch taken\n");
+        std::printf("selftest: MemorySanitizer did NOT stop a branch on an uninitialised value\n");
+        return 0;
+    }
     int bad = 0;
     /*            name                         model A  static iw topn fixed */
     bad += run_case("toa6 A16 regs",              0, 16, 1, 0, 0, 1);
