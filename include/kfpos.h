@@ -221,6 +221,41 @@ int kfpos_latch_dim(const kfpos_handle *h);
 int kfpos_get_latch(kfpos_handle *h, double *latch);
 int kfpos_set_latch(kfpos_handle *h, const double *latch);
 
+/* ---- streaming host API: epochs pipelined through kfpos_slot_count() slots of pinned host memory ----
+ * For a node that feeds epoch after epoch from the CPU (PosGenerator's table flushes, Posgenerator.cpp:155-198, batched
+ * over many tags): the synchronous calls above copy pageable arrays, turn their layout on the device and wait; here
+ * the caller ASSEMBLES each epoch directly in a slot -- host-pinned memory owned by the handle, component-major like the
+ * device layout ([max_anchors][n_tags] etc., see below) -- and submits it. A submission only enqueues: inputs go to the
+ * GPU by DMA on a copy stream, the step runs on a compute stream, status words and the poses after the epoch come back
+ * on a third; while earlier slots are in flight the caller fills the next one. Submissions execute in the order they
+ * were made.
+ *   kfpos_slot_acquire  waits until the slot's previous submission has completed (its outputs are then in the slot,
+ *                       its inputs may be overwritten) and returns the slot's pointers
+ *   kfpos_slot_submit   flags = one KFPOS_SLOT_* kind | options; dt_shared is used unless KFPOS_SLOT_DT_PER_TAG
+ *   kfpos_slot_wait     waits for the slot's submission; status / pos of the slot are valid afterwards
+ * The synchronous host API and the state accessors first wait for everything the slots have in flight. */
+typedef struct kfpos_epoch_slot {
+    int32_t  *range_mm; /* [max_anchors][n_tags] integer mm, <= 0 = absent */
+    void     *err_est;  /* [max_anchors][n_tags] kfpos_real */
+    void     *accel;    /* [3][n_tags] kfpos_real (9-state handles) */
+    void     *cov;      /* [9][n_tags] kfpos_real, row-major 3x3 index first */
+    double   *dt;       /* [n_tags], read with KFPOS_SLOT_DT_PER_TAG (negative = tag has no epoch in this submission) */
+    uint32_t *status;   /* out: [n_tags] status words of the submission */
+    double   *pos;      /* out: [3][n_tags] positions after the epoch (getPose at timeLag 0), unless KFPOS_SLOT_NO_POSE */
+} kfpos_epoch_slot;
+#define KFPOS_SLOT_TOA        0 /* kfpos_step_toa: a ranging epoch (a 9-state handle re-fuses its latched IMU sample) */
+#define KFPOS_SLOT_IMU        1 /* kfpos_step_imu: latch accel / cov, IMU-only estimate */
+#define KFPOS_SLOT_TOA_IMU    2 /* kfpos_step_toa_imu: latch + ranging epoch */
+#define KFPOS_SLOT_DT_PER_TAG 0x100 /* dt comes from the slot's dt array instead of dt_shared */
+#define KFPOS_SLOT_REUSE_ERR  0x200 /* errorEstimations are those of the previous submission: not copied again */
+#define KFPOS_SLOT_REUSE_COV  0x400 /* the accelerometer covariance is that of the previous submission (a sensor with a
+                                       fixed covariance): not copied again */
+#define KFPOS_SLOT_NO_POSE    0x800 /* do not write / return pos */
+int kfpos_slot_count(const kfpos_handle *h); /* 3: one being filled, one on the bus, one computing / returning */
+int kfpos_slot_acquire(kfpos_handle *h, int32_t slot, kfpos_epoch_slot *out);
+int kfpos_slot_submit(kfpos_handle *h, int32_t slot, int32_t flags, double dt_shared);
+int kfpos_slot_wait(kfpos_handle *h, int32_t slot);
+
 /* ---- asynchronous device-buffer API (inputs already resident in HBM) ----
  * All pointers are device pointers; `stream` is a hipStream_t (NULL = the default stream). Calls
  * enqueue work and return; the caller synchronises. Device layouts are component-major so that the

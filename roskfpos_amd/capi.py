@@ -33,7 +33,10 @@ EXPORTS = [
     "kfpos_strerror", "kfpos_version", "kfpos_timing_begin", "kfpos_timing_end",
     "kfpos_set_planar", "kfpos_step_sensor", "kfpos_step_sensor_dev", "kfpos_get_height",
     "kfpos_latch_dim", "kfpos_get_latch", "kfpos_set_latch",
+    "kfpos_slot_count", "kfpos_slot_acquire", "kfpos_slot_submit", "kfpos_slot_wait",
 ]
+SLOT_TOA, SLOT_IMU, SLOT_TOA_IMU = 0, 1, 2
+SLOT_DT_PER_TAG, SLOT_REUSE_ERR, SLOT_REUSE_COV, SLOT_NO_POSE = 0x100, 0x200, 0x400, 0x800
 
 
 class KfposError(RuntimeError):
@@ -55,6 +58,12 @@ class PlanarConfig(C.Structure):
                 ("imu_use_fixed_cov_acc", C.c_int32), ("imu_cov_acc", C.c_double),
                 ("imu_use_fixed_cov_ang_vel_z", C.c_int32), ("imu_cov_ang_vel_z", C.c_double),
                 ("mag_angle_offset", C.c_double), ("mag_cov", C.c_double)]
+
+
+class _EpochSlot(C.Structure):
+    """kfpos_epoch_slot: pointers into one slot of the handle's pinned host memory."""
+    _fields_ = [("range_mm", C.c_void_p), ("err_est", C.c_void_p), ("accel", C.c_void_p), ("cov", C.c_void_p),
+                ("dt", C.c_void_p), ("status", C.c_void_p), ("pos", C.c_void_p)]
 
 
 _lib = None
@@ -104,6 +113,10 @@ def load():
     L.kfpos_latch_dim.argtypes = [vp]
     L.kfpos_get_latch.argtypes = [vp, vp]
     L.kfpos_set_latch.argtypes = [vp, vp]
+    L.kfpos_slot_count.argtypes = [vp]
+    L.kfpos_slot_acquire.argtypes = [vp, i32, C.POINTER(_EpochSlot)]
+    L.kfpos_slot_submit.argtypes = [vp, i32, i32, f64]
+    L.kfpos_slot_wait.argtypes = [vp, i32]
     L.kfpos_timing_begin.argtypes = [vp, vp]
     L.kfpos_timing_end.argtypes = [vp, vp, C.POINTER(C.c_float)]
     L.kfpos_last_error.restype = C.c_char_p
@@ -289,6 +302,30 @@ class KfposBank:
         a = np.ascontiguousarray(latch, dtype=np.float64)
         assert a.shape == (self.T, self.lib.kfpos_latch_dim(self._h))
         self._chk(self.lib.kfpos_set_latch(self._h, a.ctypes.data if a.size else None))
+
+    # ---- streaming host API: epochs assembled in place in pinned, component-major slots ----
+    def slot_acquire(self, slot):
+        """Wait for the slot's previous submission; returns numpy views over the slot's pinned memory:
+        dict(range_mm [A][T] int32, err_est [A][T], accel [3][T], cov [9][T], dt [T], status [T], pos [3][T])."""
+        sl = _EpochSlot()
+        self._chk(self.lib.kfpos_slot_acquire(self._h, slot, C.byref(sl)))
+        T, A = self.T, self.A
+
+        def view(ptr, shape, dtype):
+            n = int(np.prod(shape))
+            buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+            return np.frombuffer(buf, dtype=dtype, count=n).reshape(shape)
+
+        return {"range_mm": view(sl.range_mm, (A, T), np.int32), "err_est": view(sl.err_est, (A, T), self.real),
+                "accel": view(sl.accel, (3, T), self.real), "cov": view(sl.cov, (9, T), self.real),
+                "dt": view(sl.dt, (T,), np.float64), "status": view(sl.status, (T,), np.uint32),
+                "pos": view(sl.pos, (3, T), np.float64)}
+
+    def slot_submit(self, slot, flags, dt_shared=0.0):
+        self._chk(self.lib.kfpos_slot_submit(self._h, slot, int(flags), float(dt_shared)))
+
+    def slot_wait(self, slot):
+        self._chk(self.lib.kfpos_slot_wait(self._h, slot))
 
     # ---- device-buffer API (pointers: ints or torch tensors; layouts in include/kfpos.h) ----
     def step_toa_dev(self, range_mm, err_est, dt, status=None, stream=None, dt_dev=None):

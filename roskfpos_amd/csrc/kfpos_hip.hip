@@ -48,6 +48,7 @@ using namespace kfpos;
 
 constexpr int WAVE = 64; /* lanes per workgroup = one wavefront */
 #define KFPOS_TRACE_CHUNK 128 /* epochs per multi-epoch launch (their dt values travel in the kernel arguments) */
+#define KFPOS_N_SLOTS 3      /* streaming host API: one slot being filled, one on the bus, one computing / returning */
 
 enum StepMode : int { MODE_TOA = 0, MODE_IMU_ONLY = 1, MODE_FUSED = 2 };
 
@@ -189,6 +190,17 @@ __device__ inline double epoch_dt(const KArgs &a, size_t t, int s) {
     return a.n_steps > 1 ? a.dt_steps[s] : (a.dt ? a.dt[t] : a.dt_shared);
 }
 
+/* a lane that sits a call out (dt < 0, or a dropped PX4Flow sample) still reports where its tag is: the trajectory /
+ * pose output of the call carries the untouched position (what getPose at timeLag 0 would return) */
+__device__ inline void skipped_lane(const KArgs &a, size_t t, bool write) {
+    if (!write) return;
+    if (a.status) a.status[t] = ST_SKIPPED;
+    if (a.traj) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) (a.traj + (size_t)k * a.T)[(uint32_t)t] = (a.pos + (size_t)k * a.T)[(uint32_t)t];
+    }
+}
+
 /* ------------------------------------------------------------------ 6-state step kernel */
 /* amdgpu_waves_per_eu(1, 2): never trade registers for a third wave per SIMD -- the LDS-resident 16-anchor variant
  * fits in 137 VGPRs when asked to, and then runs 11 % slower than with the 227 it takes at two waves (measured). */
@@ -203,7 +215,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(1, 2))) vo
     const Params pr = make_params(a);
     constexpr int NA = AS > 0 ? AS : 1;
     if (a.n_steps == 1 && a.dt && a.dt[t] < 0.0) { /* no epoch for this tag in this call */
-        if (a.status) a.status[t] = ST_SKIPPED;
+        skipped_lane(a, t, true);
         return;
     }
 
@@ -282,7 +294,7 @@ __global__ __launch_bounds__(WAVE) void k_step_toa6_coop(const KArgs a) {
     const uint32_t t32 = (uint32_t)t;
     const Params pr = make_params(a);
     if (a.n_steps == 1 && a.dt && a.dt[t] < 0.0) {
-        if (a.status && al == 0) a.status[t] = ST_SKIPPED;
+        skipped_lane(a, t, al == 0);
         return;
     }
     const bool has_anchor = al < a.A;
@@ -349,7 +361,7 @@ __global__ __launch_bounds__(WAVE) void k_step_ml(const KArgs a) {
     const uint32_t t32 = (uint32_t)t;
     const Params pr = make_params(a);
     if (a.n_steps == 1 && a.dt && a.dt[t] < 0.0) {
-        if (a.status) a.status[t] = ST_SKIPPED;
+        skipped_lane(a, t, true);
         return;
     }
     /* _previousEstimation: the per-tag seed lives in the velocity slot of the handle, it is never updated */
@@ -414,7 +426,7 @@ __global__ __launch_bounds__(WAVE) void k_step_imu9(const KArgs a) {
     const bool fresh_imu = a.mode != MODE_TOA;
     constexpr int NA = AS > 0 ? AS : 1;
     if (a.n_steps == 1 && a.dt && a.dt[t] < 0.0) { /* no epoch / sample for this tag in this call */
-        if (a.status) a.status[t] = ST_SKIPPED;
+        skipped_lane(a, t, true);
         return;
     }
 
@@ -541,7 +553,7 @@ __global__ __launch_bounds__(WAVE) void k_step_planar(const KArgs a) {
     const bool has_ranging = kind == 0;
     constexpr int NA = AS > 0 ? AS : 1;
     if (a.n_steps == 1 && a.dt && a.dt[t] < 0.0) { /* no epoch / sample for this tag in this call */
-        if (a.status) a.status[t] = ST_SKIPPED;
+        skipped_lane(a, t, true);
         return;
     }
     RawEpoch<MREAL, NA> raw;
@@ -572,7 +584,7 @@ __global__ __launch_bounds__(WAVE) void k_step_planar(const KArgs a) {
 #pragma unroll
             for (int k = 0; k < 5; ++k) f[k] = (a.sensor + k * T)[t32];
             if (!px4_sample(pr, f, m)) {
-                if (a.status) a.status[t] = ST_SKIPPED;
+                skipped_lane(a, t, true);
                 return;
             }
 #pragma unroll
@@ -622,7 +634,7 @@ __global__ __launch_bounds__(WAVE) void k_step_planar(const KArgs a) {
     for (int k = 0; k < 36; ++k) tg.P.a[k] = ldrow<REAL>(a.P, k, T, t32);
 
     /* SENS: the predicted covariance is parked in LDS, [36][lane], behind the generic kernel's epoch scratch */
-    const CovSpill8 park{lds + ((AS <= 0 && has_ranging) ? 3 * (size_t)a.A * WAVE : 0) + lane, WAVE};
+    const CovSpill8 park{lds + (AS < 0 ? 3 * (size_t)(-AS) * WAVE : ((AS == 0 && has_ranging) ? 3 * (size_t)a.A * WAVE : 0)) + lane, WAVE};
     uint32_t s = 0;
     for (int e = 0; e < a.n_steps; ++e) { /* the state stays in registers from epoch to epoch */
         const double dt = epoch_dt(a, t, e);
@@ -866,6 +878,23 @@ struct kfpos_handle {
     /* row-major staging area of the host-buffer API: one region per array of a call (bump-allocated) */
     unsigned char *d_stage = nullptr;
     size_t stage_cap = 0, stage_used = 0;
+    /* small banks (the single-tag adaptor objects, test banks): ONE host-pinned, device-mapped block holds every
+     * input and output of a host-API call in component-major form; the kernels read and write it in place over the
+     * bus, so a call is "turn the layout on the CPU, launch, synchronise" -- no hipMemcpy, no layout kernels */
+    unsigned char *sm_h = nullptr, *sm_d = nullptr;
+    size_t sm_ranges = 0, sm_err = 0, sm_accel = 0, sm_cov = 0, sm_dt = 0, sm_sensor = 0, sm_status = 0, sm_out = 0;
+    /* streaming host API: KFPOS_N_SLOTS slots of pinned host + device buffers, three streams (kfpos_slot_*) */
+    struct Slot {
+        unsigned char *host = nullptr; /* pinned block: ranges | err | accel | cov | dt | status | pos */
+        unsigned char *dev = nullptr;  /* device block, same layout */
+        hipEvent_t copied = nullptr, copied2 = nullptr, computed = nullptr, done = nullptr;
+        bool busy = false;
+    } slot[KFPOS_N_SLOTS];
+    size_t so_ranges = 0, so_err = 0, so_accel = 0, so_cov = 0, so_dt = 0, so_status = 0, so_pos = 0, so_bytes = 0;
+    hipStream_t s_copy = nullptr, s_copy2 = nullptr, s_comp = nullptr, s_back = nullptr;
+    size_t split_bytes = 0;                            /* H2D copies from this size on travel as two halves on two streams */
+    int err_slot = -1, cov_slot = -1;                  /* which slot's device block holds the current err / cov */
+    hipEvent_t err_last_use = nullptr, cov_last_use = nullptr; /* `computed` of the last submission that read them */
 };
 
 namespace {
@@ -876,7 +905,7 @@ size_t park_bytes() { return (size_t)36 * WAVE * sizeof(double); } /* 36 doubles
 void fill_args(const kfpos_handle *h, KArgs &a) {
     std::memcpy(a.anchors, h->anchors, sizeof(a.anchors));
     a.T = h->cfg.n_tags;
-    a.A = h->cfg.max_anchors;
+    a.A = h->have_anchors ? h->A : 0; /* anchors set (<= max_anchors): columns beyond them do not exist */
     a.accel_noise = h->cfg.accel_noise;
     a.jolt = h->cfg.jolt;
     a.cost_threshold = h->cfg.cost_threshold;
@@ -1099,6 +1128,57 @@ int fetch_status(kfpos_handle *h, uint32_t *status) {
     return KFPOS_OK;
 }
 
+
+/* ---- small banks: inputs and outputs in one host-pinned, device-mapped block (kfpos_handle::sm_*) ---- */
+size_t small_bank_limit() { /* elements of the range matrix (n_tags x max_anchors) up to which a bank is "small" */
+    const char *e = getenv("KFPOS_SMALL_BANK_ELEMS");
+    return e ? (size_t)atol(e) : 4096;
+}
+template <typename E>
+void rows_to_cols_host(void *dst, const void *src, size_t T, int C) {
+    const E *s = (const E *)src;
+    E *d = (E *)dst;
+    for (size_t t = 0; t < T; ++t)
+        for (int c = 0; c < C; ++c) d[(size_t)c * T + t] = s[t * C + c];
+}
+/* host row-major [T][C] -> component-major [C][T] inside the mapped block */
+void small_in(kfpos_handle *h, size_t off, const void *src, int C, size_t esz) {
+    if (esz == 4) rows_to_cols_host<uint32_t>(h->sm_h + off, src, h->cfg.n_tags, C);
+    else rows_to_cols_host<uint64_t>(h->sm_h + off, src, h->cfg.n_tags, C);
+}
+/* component-major [C][T] doubles in the mapped block -> host row-major [T][C] */
+void small_out(const kfpos_handle *h, double *dst, size_t off_doubles, int C) {
+    const size_t T = h->cfg.n_tags;
+    const double *s = (const double *)(h->sm_h + h->sm_out) + off_doubles;
+    for (size_t t = 0; t < T; ++t)
+        for (int c = 0; c < C; ++c) dst[t * C + c] = s[(size_t)c * T + t];
+}
+int small_dt(kfpos_handle *h, const double *dt, int32_t dt_len, const double **d_dt, double *shared) {
+    if (!dt || (dt_len != 1 && dt_len != h->cfg.n_tags)) return KFPOS_ERR_ARG;
+    *shared = dt[0];
+    *d_dt = nullptr;
+    if (dt_len != 1) {
+        std::memcpy(h->sm_h + h->sm_dt, dt, sizeof(double) * h->cfg.n_tags);
+        *d_dt = (const double *)(h->sm_d + h->sm_dt);
+    }
+    return KFPOS_OK;
+}
+int small_finish(kfpos_handle *h, uint32_t *status) {
+    HIPCHK(hipStreamSynchronize(nullptr)); /* the kernel's writes into the mapped block are visible now */
+    if (status) std::memcpy(status, h->sm_h + h->sm_status, sizeof(uint32_t) * h->cfg.n_tags);
+    return KFPOS_OK;
+}
+
+/* ---- streaming host API: wait for whatever the slots still have in flight ---- */
+int drain_slots(kfpos_handle *h) {
+    for (auto &sl : h->slot)
+        if (sl.busy) {
+            HIPCHK(hipEventSynchronize(sl.done));
+            sl.busy = false;
+        }
+    return KFPOS_OK;
+}
+
 /* packed index of the stored covariance entry (i, j) */
 inline int pidx(const kfpos_handle *h, int i, int j) {
     if (h->full) return i * h->n + j;
@@ -1214,6 +1294,28 @@ int kfpos_create(const kfpos_config *cfg, kfpos_handle **out) {
         kfpos_destroy(h);
         return KFPOS_ERR_HIP;
     }
+    if (T * A <= small_bank_limit()) { /* small bank: one mapped block instead of staging copies (kfpos_handle::sm_*) */
+        size_t off = 0;
+        auto region = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+        h->sm_ranges = region(A * T * sizeof(int32_t));
+        h->sm_err = region(A * T * m);
+        h->sm_accel = region(3 * T * m);
+        h->sm_cov = region(9 * T * m);
+        h->sm_dt = region(T * sizeof(double));
+        h->sm_sensor = region(24 * T * sizeof(double));
+        h->sm_status = region(T * sizeof(uint32_t));
+        h->sm_out = region((size_t)(15 + h->n + h->n * h->n) * T * sizeof(double));
+        void *hp = nullptr, *dp = nullptr;
+        if (hipHostMalloc(&hp, off, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) {
+            g_err = "hipHostMalloc(mapped block of a small bank) failed";
+            if (hp) (void)hipHostFree(hp);
+            kfpos_destroy(h);
+            return KFPOS_ERR_HIP;
+        }
+        std::memset(hp, 0, off);
+        h->sm_h = (unsigned char *)hp;
+        h->sm_d = (unsigned char *)dp;
+    }
     const bool parks = cfg->model == KFPOS_MODEL_PLANAR || (cfg->model == KFPOS_MODEL_TOA && h->full);
     if (lds_bytes(h) + (parks ? park_bytes() : 0) > 64 * 1024) {
         hipError_t e_ = hipFuncSetAttribute((const void *)step_kernel(h), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1256,8 +1358,22 @@ int kfpos_destroy(kfpos_handle *h) {
     void *ptrs[] = {h->d_pos, h->d_vel, h->d_P, h->d_imu_acc, h->d_imu_cov, h->d_flags, h->d_ranges,
                     h->d_err, h->d_accel, h->d_cov, h->d_dt, h->d_out, h->d_status, h->d_latch, h->d_sensor,
                     h->d_stage};
+    (void)hipDeviceSynchronize(); /* nothing of this handle may still be in flight (streaming slots) */
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    if (h->sm_h) (void)hipHostFree(h->sm_h);
+    for (auto &sl : h->slot) {
+        if (sl.host) (void)hipHostFree(sl.host);
+        if (sl.dev) (void)hipFree(sl.dev);
+        if (sl.copied) (void)hipEventDestroy(sl.copied);
+        if (sl.copied2) (void)hipEventDestroy(sl.copied2);
+        if (sl.computed) (void)hipEventDestroy(sl.computed);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+    }
+    if (h->s_copy) (void)hipStreamDestroy(h->s_copy);
+    if (h->s_copy2) (void)hipStreamDestroy(h->s_copy2);
+    if (h->s_comp) (void)hipStreamDestroy(h->s_comp);
+    if (h->s_back) (void)hipStreamDestroy(h->s_back);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     delete h;
@@ -1499,11 +1615,21 @@ int kfpos_step_toa(kfpos_handle *h, const int32_t *range_mm, const void *err_est
         g_err = "kfpos_set_anchors has not been called (the node drops ranges until the anchors are known, Posgenerator.cpp:92-96)";
         return KFPOS_ERR_STATE;
     }
-    stage_reset(h);
+    int rc = drain_slots(h);
+    if (rc) return rc;
     const double *d_dt;
     double shared;
-    int rc = stage_dt(h, dt, dt_len, &d_dt, &shared);
-    if (rc) return rc;
+    if (h->sm_h) {
+        if ((rc = small_dt(h, dt, dt_len, &d_dt, &shared))) return rc;
+        small_in(h, h->sm_ranges, range_mm, h->cfg.max_anchors, sizeof(int32_t));
+        small_in(h, h->sm_err, err_est, h->cfg.max_anchors, h->msz);
+        if ((rc = kfpos_step_toa_dev(h, (const int32_t *)(h->sm_d + h->sm_ranges), h->sm_d + h->sm_err, d_dt, shared,
+                                     (uint32_t *)(h->sm_d + h->sm_status), nullptr)))
+            return rc;
+        return small_finish(h, status);
+    }
+    stage_reset(h);
+    if ((rc = stage_dt(h, dt, dt_len, &d_dt, &shared))) return rc;
     if ((rc = stage_in(h, h->d_ranges, range_mm, h->cfg.max_anchors, sizeof(int32_t)))) return rc;
     if ((rc = stage_in(h, h->d_err, err_est, h->cfg.max_anchors, h->msz))) return rc;
     if ((rc = kfpos_step_toa_dev(h, h->d_ranges, h->d_err, d_dt, shared, h->d_status, nullptr))) return rc;
@@ -1519,10 +1645,20 @@ int kfpos_step_imu(kfpos_handle *h, const void *accel, const void *cov, const do
         return KFPOS_OK;
     }
     const double *d_dt;
-    stage_reset(h);
     double shared;
-    int rc = stage_dt(h, dt, dt_len, &d_dt, &shared);
+    int rc = drain_slots(h);
     if (rc) return rc;
+    if (h->sm_h) {
+        if ((rc = small_dt(h, dt, dt_len, &d_dt, &shared))) return rc;
+        small_in(h, h->sm_accel, accel, 3, h->msz);
+        small_in(h, h->sm_cov, cov, 9, h->msz);
+        if ((rc = kfpos_step_imu_dev(h, h->sm_d + h->sm_accel, h->sm_d + h->sm_cov, d_dt, shared,
+                                     (uint32_t *)(h->sm_d + h->sm_status), nullptr)))
+            return rc;
+        return small_finish(h, status);
+    }
+    stage_reset(h);
+    if ((rc = stage_dt(h, dt, dt_len, &d_dt, &shared))) return rc;
     if ((rc = stage_in(h, h->d_accel, accel, 3, h->msz))) return rc;
     if ((rc = stage_in(h, h->d_cov, cov, 9, h->msz))) return rc;
     if ((rc = kfpos_step_imu_dev(h, h->d_accel, h->d_cov, d_dt, shared, h->d_status, nullptr))) return rc;
@@ -1539,13 +1675,193 @@ int kfpos_step_sensor(kfpos_handle *h, int32_t kind, const double *data, const d
         return KFPOS_OK;
     }
     const double *d_dt;
-    stage_reset(h);
     double shared;
-    int rc = stage_dt(h, dt, dt_len, &d_dt, &shared);
+    int rc = drain_slots(h);
     if (rc) return rc;
+    if (h->sm_h) {
+        if ((rc = small_dt(h, dt, dt_len, &d_dt, &shared))) return rc;
+        small_in(h, h->sm_sensor, data, C, sizeof(double));
+        if ((rc = kfpos_step_sensor_dev(h, kind, (const double *)(h->sm_d + h->sm_sensor), d_dt, shared,
+                                        (uint32_t *)(h->sm_d + h->sm_status), nullptr)))
+            return rc;
+        return small_finish(h, status);
+    }
+    stage_reset(h);
+    if ((rc = stage_dt(h, dt, dt_len, &d_dt, &shared))) return rc;
     if ((rc = stage_in(h, h->d_sensor, data, C, sizeof(double)))) return rc;
     if ((rc = kfpos_step_sensor_dev(h, kind, h->d_sensor, d_dt, shared, h->d_status, nullptr))) return rc;
     return fetch_status(h, status);
+}
+
+
+/* ---- streaming host API (kfpos.h: kfpos_slot_*) ---- */
+static int slots_init(kfpos_handle *h) {
+    if (h->s_copy) return KFPOS_OK;
+    {
+        const char *e = getenv("KFPOS_SLOT_SPLIT_BYTES");
+        h->split_bytes = e ? (size_t)atol(e) : 0; /* off: measured slower inside the pipeline (profiles/r02i_*) */
+    }
+    const size_t T = h->cfg.n_tags, A = h->cfg.max_anchors, m = h->msz;
+    size_t off = 0;
+    auto region = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    h->so_ranges = region(A * T * sizeof(int32_t));
+    h->so_err = region(A * T * m);
+    h->so_accel = region(3 * T * m);
+    h->so_cov = region(9 * T * m);
+    h->so_dt = region(T * sizeof(double));
+    h->so_status = region(T * sizeof(uint32_t));
+    h->so_pos = region(3 * T * sizeof(double));
+    h->so_bytes = off;
+    HIPCHK(hipStreamCreateWithFlags(&h->s_copy, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&h->s_copy2, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&h->s_comp, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&h->s_back, hipStreamNonBlocking));
+    for (auto &sl : h->slot) {
+        HIPCHK(hipHostMalloc((void **)&sl.host, off, hipHostMallocDefault));
+        HIPCHK(hipMalloc((void **)&sl.dev, off));
+        std::memset(sl.host, 0, off);
+        HIPCHK(hipMemset(sl.dev, 0, off));
+        HIPCHK(hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&sl.copied2, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&sl.computed, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    }
+    HIPCHK(hipDeviceSynchronize()); /* whatever the other entry points queued on the default stream comes first */
+    return KFPOS_OK;
+}
+
+int kfpos_slot_count(const kfpos_handle *h) { return h ? KFPOS_N_SLOTS : 0; }
+
+int kfpos_slot_acquire(kfpos_handle *h, int32_t slot, kfpos_epoch_slot *out) {
+    g_err.clear();
+    if (!h || !out || slot < 0 || slot >= KFPOS_N_SLOTS) return KFPOS_ERR_ARG;
+    const int rc = slots_init(h);
+    if (rc) return rc;
+    auto &sl = h->slot[slot];
+    if (sl.busy) { /* its last submission: inputs consumed, outputs delivered */
+        HIPCHK(hipEventSynchronize(sl.done));
+        sl.busy = false;
+    }
+    out->range_mm = (int32_t *)(sl.host + h->so_ranges);
+    out->err_est = sl.host + h->so_err;
+    out->accel = sl.host + h->so_accel;
+    out->cov = sl.host + h->so_cov;
+    out->dt = (double *)(sl.host + h->so_dt);
+    out->status = (uint32_t *)(sl.host + h->so_status);
+    out->pos = (double *)(sl.host + h->so_pos);
+    return KFPOS_OK;
+}
+
+int kfpos_slot_submit(kfpos_handle *h, int32_t slot, int32_t flags, double dt_shared) {
+    g_err.clear();
+    if (!h || slot < 0 || slot >= KFPOS_N_SLOTS) return KFPOS_ERR_ARG;
+    if (!h->s_copy || h->slot[slot].busy) {
+        g_err = "kfpos_slot_submit: acquire the slot first (kfpos_slot_acquire)";
+        return KFPOS_ERR_STATE;
+    }
+    const int kind = flags & 0xff;
+    if (kind != KFPOS_SLOT_TOA && kind != KFPOS_SLOT_IMU && kind != KFPOS_SLOT_TOA_IMU) return KFPOS_ERR_ARG;
+    if (h->cfg.model == KFPOS_MODEL_PLANAR && kind != KFPOS_SLOT_TOA) return KFPOS_ERR_MODEL; /* its sensors: kfpos_step_sensor */
+    const bool imu9 = h->cfg.model == KFPOS_MODEL_TOA_IMU;
+    if (kind == KFPOS_SLOT_TOA_IMU && !imu9) return KFPOS_ERR_MODEL;
+    const bool has_rng = kind != KFPOS_SLOT_IMU, has_imu = imu9 && kind != KFPOS_SLOT_TOA;
+    if (kind == KFPOS_SLOT_IMU && !imu9) { /* KalmanFilterTOA::newIMUMeasurement is empty */
+        std::memset(h->slot[slot].host + h->so_status, 0, sizeof(uint32_t) * h->cfg.n_tags);
+        return KFPOS_OK;
+    }
+    if (has_rng && !h->have_anchors) {
+        g_err = "kfpos_set_anchors has not been called";
+        return KFPOS_ERR_STATE;
+    }
+    auto &sl = h->slot[slot];
+    const size_t T = h->cfg.n_tags, A = h->cfg.max_anchors, m = h->msz;
+    /* 1. inputs: pinned host -> device on the copy stream. A complete fused epoch is one contiguous block of the slot
+     * (ranges | err | accel | cov | dt): one DMA instead of five. Measured on this platform (tools/exp/h2d_probe.hip,
+     * profiles/r02g_*): a lone 7.3 MB copy moves at 27-35 GB/s while the GPU is otherwise idle and at 53 GB/s while a
+     * kernel is running; two halves on two streams reach 55 GB/s when ALONE but were slower inside this pipeline
+     * (KFPOS_SLOT_SPLIT_BYTES=n turns that on for copies of n bytes and more; default off). */
+    bool second = false;
+    auto h2d = [&](size_t off, size_t bytes) -> hipError_t {
+        if (h->split_bytes == 0 || bytes < h->split_bytes) return hipMemcpyAsync(sl.dev + off, sl.host + off, bytes, hipMemcpyHostToDevice, h->s_copy);
+        const size_t half = (bytes / 2 + 255) & ~(size_t)255;
+        hipError_t e = hipMemcpyAsync(sl.dev + off, sl.host + off, half, hipMemcpyHostToDevice, h->s_copy);
+        if (e != hipSuccess) return e;
+        second = true;
+        return hipMemcpyAsync(sl.dev + off + half, sl.host + off + half, bytes - half, hipMemcpyHostToDevice, h->s_copy2);
+    };
+    /* a slot's device copy of err / cov may still be read by a later submission of another slot that reused it */
+    auto guard = [&](hipEvent_t last_use) -> hipError_t {
+        hipError_t e = hipStreamWaitEvent(h->s_copy, last_use, 0);
+        return e != hipSuccess ? e : hipStreamWaitEvent(h->s_copy2, last_use, 0);
+    };
+    const bool up_err = has_rng && !(flags & KFPOS_SLOT_REUSE_ERR), up_cov = has_imu && !(flags & KFPOS_SLOT_REUSE_COV);
+    if (has_rng && !up_err && h->err_slot < 0) {
+        g_err = "KFPOS_SLOT_REUSE_ERR before any errorEstimation was submitted";
+        return KFPOS_ERR_STATE;
+    }
+    if (has_imu && !up_cov && h->cov_slot < 0) {
+        g_err = "KFPOS_SLOT_REUSE_COV before any covariance was submitted";
+        return KFPOS_ERR_STATE;
+    }
+    if (up_err && h->err_slot == slot && h->err_last_use) HIPCHK(guard(h->err_last_use));
+    if (up_cov && h->cov_slot == slot && h->cov_last_use) HIPCHK(guard(h->cov_last_use));
+    if (up_err && up_cov) { /* the whole block in one go */
+        const size_t end = (flags & KFPOS_SLOT_DT_PER_TAG) ? h->so_dt + T * sizeof(double) : h->so_cov + 9 * T * m;
+        HIPCHK(h2d(h->so_ranges, end - h->so_ranges));
+    } else {
+        if (has_rng) HIPCHK(h2d(h->so_ranges, up_err ? h->so_err + A * T * m - h->so_ranges : A * T * sizeof(int32_t)));
+        if (has_imu) HIPCHK(h2d(h->so_accel, up_cov ? h->so_cov + 9 * T * m - h->so_accel : 3 * T * m));
+        if (flags & KFPOS_SLOT_DT_PER_TAG) HIPCHK(h2d(h->so_dt, T * sizeof(double)));
+    }
+    if (up_err) h->err_slot = slot;
+    if (up_cov) h->cov_slot = slot;
+    HIPCHK(hipEventRecord(sl.copied, h->s_copy));
+    if (second) HIPCHK(hipEventRecord(sl.copied2, h->s_copy2));
+    /* 2. the step, on the compute stream (submissions run in order: the filter state is sequential) */
+    HIPCHK(hipStreamWaitEvent(h->s_comp, sl.copied, 0));
+    if (second) HIPCHK(hipStreamWaitEvent(h->s_comp, sl.copied2, 0));
+    KArgs a;
+    fill_args(h, a);
+    a.mode = kind == KFPOS_SLOT_TOA ? MODE_TOA : (kind == KFPOS_SLOT_IMU ? MODE_IMU_ONLY : MODE_FUSED);
+    a.latch = 1;
+    if (has_rng) {
+        a.ranges = (const int32_t *)(sl.dev + h->so_ranges);
+        a.err = h->slot[h->err_slot].dev + h->so_err;
+    }
+    if (has_imu) {
+        a.accel = sl.dev + h->so_accel;
+        a.cov = h->slot[h->cov_slot].dev + h->so_cov;
+    }
+    a.dt = (flags & KFPOS_SLOT_DT_PER_TAG) ? (const double *)(sl.dev + h->so_dt) : nullptr;
+    a.dt_shared = dt_shared;
+    a.status = (uint32_t *)(sl.dev + h->so_status);
+    const bool want_pose = !(flags & KFPOS_SLOT_NO_POSE);
+    a.traj = want_pose ? (double *)(sl.dev + h->so_pos) : nullptr;
+    const int rc = launch_step(h, a, h->s_comp);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(sl.computed, h->s_comp));
+    if (has_rng) h->err_last_use = sl.computed;
+    if (has_imu) h->cov_last_use = sl.computed;
+    /* 3. outputs: device -> pinned host, on the return stream */
+    HIPCHK(hipStreamWaitEvent(h->s_back, sl.computed, 0));
+    /* status words and poses sit side by side in the slot: one copy */
+    HIPCHK(hipMemcpyAsync(sl.host + h->so_status, sl.dev + h->so_status,
+                          want_pose ? h->so_pos + 3 * T * sizeof(double) - h->so_status : T * sizeof(uint32_t),
+                          hipMemcpyDeviceToHost, h->s_back));
+    HIPCHK(hipEventRecord(sl.done, h->s_back));
+    sl.busy = true;
+    return KFPOS_OK;
+}
+
+int kfpos_slot_wait(kfpos_handle *h, int32_t slot) {
+    g_err.clear();
+    if (!h || slot < 0 || slot >= KFPOS_N_SLOTS) return KFPOS_ERR_ARG;
+    auto &sl = h->slot[slot];
+    if (sl.busy) {
+        HIPCHK(hipEventSynchronize(sl.done));
+        sl.busy = false;
+    }
+    return KFPOS_OK;
 }
 
 int kfpos_get_height(kfpos_handle *h, double *z) {
@@ -1563,11 +1879,24 @@ int kfpos_step_toa_imu(kfpos_handle *h, const int32_t *range_mm, const void *err
     if (!h || !range_mm || !err_est || !accel || !cov) return KFPOS_ERR_ARG;
     if (h->cfg.model != KFPOS_MODEL_TOA_IMU) return KFPOS_ERR_MODEL;
     if (!h->have_anchors) return KFPOS_ERR_STATE;
-    stage_reset(h);
     const double *d_dt;
     double shared;
-    int rc = stage_dt(h, dt, dt_len, &d_dt, &shared);
+    int rc = drain_slots(h);
     if (rc) return rc;
+    if (h->sm_h) {
+        if ((rc = small_dt(h, dt, dt_len, &d_dt, &shared))) return rc;
+        small_in(h, h->sm_ranges, range_mm, h->cfg.max_anchors, sizeof(int32_t));
+        small_in(h, h->sm_err, err_est, h->cfg.max_anchors, h->msz);
+        small_in(h, h->sm_accel, accel, 3, h->msz);
+        small_in(h, h->sm_cov, cov, 9, h->msz);
+        if ((rc = kfpos_step_toa_imu_dev(h, (const int32_t *)(h->sm_d + h->sm_ranges), h->sm_d + h->sm_err,
+                                         h->sm_d + h->sm_accel, h->sm_d + h->sm_cov, 1, d_dt, shared,
+                                         (uint32_t *)(h->sm_d + h->sm_status), nullptr)))
+            return rc;
+        return small_finish(h, status);
+    }
+    stage_reset(h);
+    if ((rc = stage_dt(h, dt, dt_len, &d_dt, &shared))) return rc;
     if ((rc = stage_in(h, h->d_ranges, range_mm, h->cfg.max_anchors, sizeof(int32_t)))) return rc;
     if ((rc = stage_in(h, h->d_err, err_est, h->cfg.max_anchors, h->msz))) return rc;
     if ((rc = stage_in(h, h->d_accel, accel, 3, h->msz))) return rc;
@@ -1581,8 +1910,25 @@ int kfpos_step_toa_imu(kfpos_handle *h, const int32_t *range_mm, const void *err
 static int get_pose_host(kfpos_handle *h, double dt_ahead, const double *dt_each, double *pos, double *cov3x3,
                          double *vel, uint32_t *status) {
     if (!h) return KFPOS_ERR_ARG;
-    stage_reset(h);
     const size_t T = h->cfg.n_tags;
+    int rc0 = drain_slots(h);
+    if (rc0) return rc0;
+    if (h->sm_h) {
+        const double *d_each = nullptr;
+        if (dt_each) {
+            std::memcpy(h->sm_h + h->sm_dt, dt_each, sizeof(double) * T);
+            d_each = (const double *)(h->sm_d + h->sm_dt);
+        }
+        double *o = (double *)(h->sm_d + h->sm_out);
+        const int rc = launch_pose(h, dt_ahead, d_each, o, o + 3 * T, o + 12 * T, (uint32_t *)(h->sm_d + h->sm_status), nullptr);
+        if (rc) return rc;
+        if ((rc0 = small_finish(h, status))) return rc0;
+        if (pos) small_out(h, pos, 0, 3);
+        if (cov3x3) small_out(h, cov3x3, 3 * T, 9);
+        if (vel) small_out(h, vel, 12 * T, 3);
+        return KFPOS_OK;
+    }
+    stage_reset(h);
     double *dp = h->d_out, *dc = h->d_out + 3 * T, *dv = h->d_out + 12 * T;
     const double *d_each = nullptr;
     if (dt_each) {
@@ -1616,8 +1962,25 @@ int kfpos_get_predicted(kfpos_handle *h, const double *dt_ahead, int32_t dt_len,
                         uint32_t *status) {
     g_err.clear();
     if (!h || !dt_ahead || !x || !P || (dt_len != 1 && dt_len != h->cfg.n_tags)) return KFPOS_ERR_ARG;
-    stage_reset(h);
     const size_t T = h->cfg.n_tags, n = h->n;
+    int rc0 = drain_slots(h);
+    if (rc0) return rc0;
+    if (h->sm_h) {
+        const double *d_each = nullptr;
+        if (dt_len > 1) {
+            std::memcpy(h->sm_h + h->sm_dt, dt_ahead, sizeof(double) * T);
+            d_each = (const double *)(h->sm_d + h->sm_dt);
+        }
+        double *o = (double *)(h->sm_d + h->sm_out) + 15 * T;
+        if ((rc0 = launch_pose(h, dt_ahead[0], d_each, nullptr, nullptr, nullptr, (uint32_t *)(h->sm_d + h->sm_status),
+                               nullptr, o, o + n * T)))
+            return rc0;
+        if ((rc0 = small_finish(h, status))) return rc0;
+        small_out(h, x, 15 * T, (int)n);
+        small_out(h, P, 15 * T + n * T, (int)(n * n));
+        return KFPOS_OK;
+    }
+    stage_reset(h);
     /* component-major results + their row-major turn, all from the staging area: reserve the lot first so that no
      * region moves while another is in use */
     const size_t bx = n * T * sizeof(double), bP = n * n * T * sizeof(double);
