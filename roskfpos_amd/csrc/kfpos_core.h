@@ -56,6 +56,15 @@
 #define KFPOS_WAVE_ALL(pred) (pred)
 #endif
 
+/* The instruction scheduler may not move anything across this point (device code; nothing on the host). Used where
+ * a large object has just been parked outside the register file: without the fence the scheduler overlaps what comes
+ * next with the parking stores and both live sets coexist. */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define KFPOS_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define KFPOS_SCHED_FENCE() ((void)0)
+#endif
+
 namespace kfpos {
 
 /* per-tag status word (include/kfpos.h repeats these as KFPOS_ST_*) */
@@ -146,6 +155,17 @@ KFPOS_FN double kf_mm_to_m(int32_t mm) {
 #else
     return (double)mm / 1000;
 #endif
+}
+
+/* The reference's convergence test  fabs(cost - c) / cost < tol  (KalmanFilterTOA.cpp:307, KalmanFilterTOAIMU.cpp:316)
+ * with the same decision for every input, without paying an IEEE division (a dozen instructions) in every iteration:
+ * the product form decides unless the two sides are within a few ulps of each other, and only then -- wave-uniformly,
+ * practically never -- is the quotient formed. NaN / 0 / inf operands fall through to the exact form as well. */
+KFPOS_FN bool rel_change_below(double cost, double c, double tol) {
+    const double lhs = fabs(cost - c), rhs = tol * cost;
+    const bool clear = cost > 0.0 && fabs(lhs - rhs) > 1e-13 * rhs; /* false for NaN and for cost <= 0 or inf */
+    if (KFPOS_WAVE_ALL(clear)) return lhs < rhs;
+    return lhs / cost < tol;
 }
 
 /* std::max as the reference uses it: (a < b) ? b : a (matters for NaN) */

@@ -9,6 +9,9 @@
 namespace kfpos {
 
 /* ================================================================== 9-state filter (KalmanFilterTOAIMU) */
+/* smallest LDL' pivot of P_ee, relative to its diagonal entry, for which the information-form iteration is used */
+constexpr double INFO_FORM_MIN_PIVOT = 1e-7;
+
 struct Tag9 {
     double pos[3], vel[3];
     Cov<9, true> P;
@@ -16,13 +19,16 @@ struct Tag9 {
 struct Imu {
     bool has;      /* hasImuMeasurement */
     double acc[3]; /* linearAcceleration */
-    double ci[6];  /* inverse Cholesky factor of the covariance, lower {00,10,20,11,21,22}: Sigma^-1 = Ci' Ci */
+    double *ci;    /* inverse Cholesky factor of the covariance, lower {00,10,20,11,21,22}: Sigma^-1 = Ci' Ci; entry k
+                      at ci[k * ci_stride]. Used once per step (covariance update) and constant over a launch, so it
+                      waits outside the register file (LDS on the GPU) */
+    int ci_stride;
     double wi[6];  /* Sigma^-1 itself, symmetric {00,01,02,11,12,22} */
 };
 
 /* Sigma (row-major 3x3, symmetric positive definite; the lower triangle is read) -> Ci with
  * Sigma^-1 = Ci' Ci, and Sigma^-1 = Ci' Ci itself */
-KFPOS_FN void imu_whitener(const double s[9], double ci[6], double wi[6]) {
+KFPOS_FN void imu_whitener(const double s[9], double *ci, int ci_stride, double wi[6]) {
     double c00, c11, c22, i00, i11, i22;
     kf_sqrt_rsqrt(s[0], c00, i00);
     const double c10 = s[3] * i00, c20 = s[6] * i00;
@@ -32,7 +38,8 @@ KFPOS_FN void imu_whitener(const double s[9], double ci[6], double wi[6]) {
     const double i10 = -c10 * i00 * i11;
     const double i21 = -c21 * i11 * i22;
     const double i20 = -(c20 * i00 + c21 * i10) * i22;
-    ci[0] = i00; ci[1] = i10; ci[2] = i20; ci[3] = i11; ci[4] = i21; ci[5] = i22;
+    ci[0] = i00; ci[ci_stride] = i10; ci[2 * ci_stride] = i20; ci[3 * ci_stride] = i11; ci[4 * ci_stride] = i21;
+    ci[5 * ci_stride] = i22;
     wi[0] = i00 * i00 + i10 * i10 + i20 * i20;
     wi[1] = i10 * i11 + i20 * i21;
     wi[2] = i20 * i22;
@@ -106,9 +113,10 @@ struct Factor9 {
 KFPOS_FN void factor9(const double mr[6], const double acc[3], const Imu &imu, Factor9 &f) {
     chol3_psd(mr, f.lr, f.ilr);
     if (imu.has) {
-        f.la[0] = acc[0] * imu.ci[0]; f.la[1] = acc[0] * imu.ci[1]; f.la[2] = acc[0] * imu.ci[2];
-        f.la[3] = acc[1] * imu.ci[3]; f.la[4] = acc[1] * imu.ci[4];
-        f.la[5] = acc[2] * imu.ci[5];
+        const int cs = imu.ci_stride;
+        f.la[0] = acc[0] * imu.ci[0]; f.la[1] = acc[0] * imu.ci[cs]; f.la[2] = acc[0] * imu.ci[2 * cs];
+        f.la[3] = acc[1] * imu.ci[3 * cs]; f.la[4] = acc[1] * imu.ci[4 * cs];
+        f.la[5] = acc[2] * imu.ci[5 * cs];
     } else {
         KFPOS_UNROLL
         for (int k = 0; k < 6; ++k) f.la[k] = 0.0;
@@ -130,7 +138,7 @@ KFPOS_FN double L9(const Factor9 &f, int k, int l) {
 }
 
 struct Iekf9Out {
-    double x[9];
+    double w[6];      /* w of the last gain iteration: the updated state is xhat + P E' w */
     double mrlast[6], dlast[3];
     double cost;
     int gain_iters, ml_iters;
@@ -156,23 +164,24 @@ KFPOS_FN void iekf9_weights(const double xhat[9], SC &sc, const Params &pr, bool
 /* second part (:296-336): the IEKF loop, up to the covariance update */
 /* DIAG: the accelerometer covariance of every lane of the wavefront is diagonal (the usual case: sensor_msgs::Imu
  * carries diag covariances), so Sigma^-1 and M_a = D Sigma^-1 D are diagonal: their 3x3 products collapse to
- * scalings (about 90 of the 725 instructions of an iteration). Same results: the skipped terms are exact zeros. */
-template <bool DIAG, class SC>
+ * scalings (about 90 of the 725 instructions of an iteration). Same results: the skipped terms are exact zeros.
+ * RANGING: the call carries ranging rows (compile-time: the sums of the sweep then need no zero start value and the
+ * loop body no branch around it). */
+template <bool DIAG, bool RANGING, class SC>
 KFPOS_FN void iekf9(const double xhat[9], const Cov<9, true> &P, SC &sc, const Params &pr,
-                    bool has_ranging, const Imu &imu, int max_steps, double tol, Iekf9Out &o) {
-    const uint64_t drop = has_ranging ? 0ull : ~0ull;
+                    const Imu &imu, int max_steps, double tol, Iekf9Out &o) {
     double p[3] = {xhat[0], xhat[1], xhat[2]}, acc[3] = {xhat[6], xhat[7], xhat[8]};
-    double de[6] = {0, 0, 0, 0, 0, 0}; /* delta on the updated components (position, acceleration) */
+    double ve[6] = {0, 0, 0, 0, 0, 0}; /* P_ee w = x_e - xhat_e = -delta on the updated components (position, acceleration) */
     double wl[6] = {0, 0, 0, 0, 0, 0};
     double qd = 0.0, cost = 1e20;
-    const bool pivot = has_ranging && illconditioned(sc, pr, P);
+    const bool pivot = RANGING && illconditioned(sc, pr, P);
     KFPOS_UNROLL
     for (int k = 0; k < 6; ++k) o.mrlast[k] = 0.0;
     o.dlast[0] = o.dlast[1] = o.dlast[2] = 0.0;
     o.gain_iters = 0;
     for (int iter = 0; iter < max_steps; ++iter) {
         double c = qd, m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0, u0 = 0, u1 = 0, u2 = 0;
-        if (has_ranging) {
+        if constexpr (RANGING) {
             for_anchors<SC>(pr, [&](int a) {
                 const double dx = p[0] - pr.anchors[3 * a], dy = p[1] - pr.anchors[3 * a + 1],
                              dz = p[2] - pr.anchors[3 * a + 2];
@@ -188,16 +197,16 @@ KFPOS_FN void iekf9(const double xhat[9], const Cov<9, true> &P, SC &sc, const P
                 m3 += wy * gy; m4 += wy * gz; m5 += wz * gz;
             });
         }
-        /* u_r = G' R^-1 (y - G delta_p) = G' R^-1 y - M_r delta_p: the delta term once per pass */
+        /* u_r = G' R^-1 (y - G delta_p) = G' R^-1 y + M_r (P_ee w)_p: the delta term once per pass */
         const double m[6] = {m0, m1, m2, m3, m4, m5},
-                     u[3] = {u0 - (m0 * de[0] + m1 * de[1] + m2 * de[2]), u1 - (m1 * de[0] + m3 * de[1] + m4 * de[2]),
-                             u2 - (m2 * de[0] + m4 * de[1] + m5 * de[2])};
+                     u[3] = {u0 + (m0 * ve[0] + m1 * ve[1] + m2 * ve[2]), u1 + (m1 * ve[0] + m3 * ve[1] + m4 * ve[2]),
+                             u2 + (m2 * ve[0] + m4 * ve[1] + m5 * ve[2])};
         /* IMU rows: y_a = z_a - a, cost += y_a' Sigma^-1 y_a, u_a = D Sigma^-1 (y_a - D delta_a),
          * M_a = D Sigma^-1 D with D = diag(a) (sic, KalmanFilterTOAIMU.cpp:441-473) */
         double ua[3] = {0, 0, 0}, ma[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
         if (imu.has) {
             const double ya[3] = {imu.acc[0] - acc[0], imu.acc[1] - acc[1], imu.acc[2] - acc[2]};
-            const double va[3] = {ya[0] - acc[0] * de[3], ya[1] - acc[1] * de[4], ya[2] - acc[2] * de[5]};
+            const double va[3] = {ya[0] + acc[0] * ve[3], ya[1] + acc[1] * ve[4], ya[2] + acc[2] * ve[5]};
             if constexpr (DIAG) {
                 const double wd[3] = {imu.wi[0], imu.wi[3], imu.wi[5]};
                 KFPOS_UNROLL
@@ -221,7 +230,7 @@ KFPOS_FN void iekf9(const double xhat[9], const Cov<9, true> &P, SC &sc, const P
                 }
             }
         }
-        if (fabs(cost - c) / cost < tol) break; /* KalmanFilterTOAIMU.cpp:316 */
+        if (rel_change_below(cost, c, tol)) break; /* KalmanFilterTOAIMU.cpp:316 */
         cost = c;
         KFPOS_UNROLL
         for (int k = 0; k < 6; ++k) o.mrlast[k] = m[k];
@@ -304,7 +313,7 @@ KFPOS_FN void iekf9(const double xhat[9], const Cov<9, true> &P, SC &sc, const P
             double v = 0.0;
             KFPOS_UNROLL
             for (int k = 0; k < 6; ++k) v += P(e9(i), e9(k)) * wl[k];
-            de[i] = -v;
+            ve[i] = v;
             qd += wl[i] * v;
             if (i < 3) p[i] = xhat[i] + v;
             else acc[i - 3] = xhat[3 + i] + v;
@@ -312,12 +321,196 @@ KFPOS_FN void iekf9(const double xhat[9], const Cov<9, true> &P, SC &sc, const P
         o.gain_iters++;
     }
     KFPOS_UNROLL
-    for (int i = 0; i < 9; ++i) {
-        double v = 0.0;
+    for (int k = 0; k < 6; ++k) o.w[k] = wl[k];
+    o.cost = cost;
+}
+
+/* ---- information-form gain iteration ------------------------------------------------------------------------
+ * With B = P_ee (the 6x6 block of the predicted covariance on position and acceleration) invertible, the state shift
+ * v = P_ee w of a gain iteration solves the SYMMETRIC POSITIVE DEFINITE system
+ *        (B^-1 + M) v = u,          M = blockdiag(M_r, M_a),  u = H' R^-1 (y - H delta)
+ * (multiply w = (I + M B)^-1 u by B), and w = u - M v. B is fixed during the iterations of a step, so B^-1 is formed
+ * once per step and an iteration costs one 6x6 LDL' solve (~140 instructions) instead of the two 3x3-block
+ * eliminations on the non-symmetric I + M B plus the product P_ee w (~360): 700 -> ~510 instructions per iteration.
+ * No pivoting is needed (SPD), so the adjugate / pivoted split of the other form does not exist here. B is singular
+ * right after a fixed start (P0 = 0, Q has rank 1 per axis) and close to it for a few epochs: sym6_inverse() says
+ * so, and such steps take the (I + M B) form below, which needs no inverse of B. */
+KFPOS_HD constexpr int s6(int i, int j) { return Cov<6, true>::idx(i, j); }
+
+/* LDL' of a symmetric 6x6 (packed upper): unit lower L (strictly lower entries), pivots d, reciprocals id.
+ * Returns false when a pivot is not safely positive: d_j <= rel * a_jj. */
+KFPOS_FN bool ldl6(const Cov<6, true> &a, double L[6][6], double id[6], double rel) {
+    bool ok = true;
+    double d[6];
+    KFPOS_UNROLL
+    for (int j = 0; j < 6; ++j) {
+        double v[6], dj = a(j, j);
         KFPOS_UNROLL
-        for (int k = 0; k < 6; ++k) v += P(i, e9(k)) * wl[k];
-        o.x[i] = xhat[i] + v;
+        for (int k = 0; k < j; ++k) { v[k] = L[j][k] * d[k]; dj -= L[j][k] * v[k]; }
+        ok = ok && (dj > rel * a(j, j));
+        d[j] = dj;
+        id[j] = kf_rcp(dj > 0.0 ? dj : 1.0);
+        KFPOS_UNROLL
+        for (int i = j + 1; i < 6; ++i) {
+            double t = a(i, j);
+            KFPOS_UNROLL
+            for (int k = 0; k < j; ++k) t -= L[i][k] * v[k];
+            L[i][j] = t * id[j];
+        }
     }
+    return ok;
+}
+/* inverse of a symmetric positive definite 6x6, packed entry k written to out[k * stride] as soon as it is formed (the
+ * caller parks it in LDS: holding all 21 in registers next to L and L^-1 is what made this kernel spill); false: not
+ * safely invertible (out then holds nothing useful) */
+KFPOS_FN bool sym6_inverse(const Cov<6, true> &a, double *out, int stride, double rel) {
+    double L[6][6], id[6], W[6][6]; /* W = L^-1, unit lower */
+    const bool ok = ldl6(a, L, id, rel);
+    KFPOS_UNROLL
+    for (int j = 0; j < 6; ++j) {
+        KFPOS_UNROLL
+        for (int i = j + 1; i < 6; ++i) {
+            double t = L[i][j];
+            KFPOS_UNROLL
+            for (int k = j + 1; k < i; ++k) t += L[i][k] * W[k][j];
+            W[i][j] = -t;
+        }
+    }
+    KFPOS_UNROLL
+    for (int i = 0; i < 6; ++i) {
+        KFPOS_UNROLL
+        for (int j = i; j < 6; ++j) { /* sum over k >= j of W(k,i) W(k,j) / d_k, W(k,k) = 1 */
+            double t = (i == j ? 1.0 : W[j][i]) * id[j];
+            KFPOS_UNROLL
+            for (int k = j + 1; k < 6; ++k) t += W[k][i] * W[k][j] * id[k];
+            out[s6(i, j) * stride] = t;
+        }
+    }
+    return ok;
+}
+/* x = K^-1 b for a symmetric positive definite 6x6 K, by 3x3 blocks: K = [Kpp Kpa; Kpa' Kaa], Kpp and the Schur
+ * complement Kaa - Kpa' Kpp^-1 Kpa (both SPD) inverted through their cofactors. About as many operations as an LDL'
+ * solve, but a dependency chain a third as long (two reciprocals instead of six on it, every cofactor independent of
+ * the others) -- with one wavefront per SIMD nothing else hides that latency. */
+KFPOS_HD constexpr int s3(int i, int j) { return i <= j ? (i == 0 ? j : (i == 1 ? 2 + j : 5)) : (j == 0 ? i : (j == 1 ? 2 + i : 5)); }
+KFPOS_FN void sym6_solve(const Cov<6, true> &K, const double b[6], double x[6]) {
+    const double kpp[6] = {K(0, 0), K(0, 1), K(0, 2), K(1, 1), K(1, 2), K(2, 2)};
+    double c1[6], c2[6];
+    const double id1 = kf_rcp(sym3_cofactors(kpp, c1));
+    double X[3][3], y1[3]; /* Kpp^-1 [Kpa | b_p] */
+    KFPOS_UNROLL
+    for (int i = 0; i < 3; ++i) {
+        y1[i] = (c1[s3(i, 0)] * b[0] + c1[s3(i, 1)] * b[1] + c1[s3(i, 2)] * b[2]) * id1;
+        KFPOS_UNROLL
+        for (int j = 0; j < 3; ++j)
+            X[i][j] = (c1[s3(i, 0)] * K(0, 3 + j) + c1[s3(i, 1)] * K(1, 3 + j) + c1[s3(i, 2)] * K(2, 3 + j)) * id1;
+    }
+    double S[6], rhs[3];
+    KFPOS_UNROLL
+    for (int i = 0; i < 3; ++i) {
+        rhs[i] = b[3 + i] - (K(0, 3 + i) * y1[0] + K(1, 3 + i) * y1[1] + K(2, 3 + i) * y1[2]);
+        KFPOS_UNROLL
+        for (int j = i; j < 3; ++j)
+            S[s3(i, j)] = K(3 + i, 3 + j) - (K(0, 3 + i) * X[0][j] + K(1, 3 + i) * X[1][j] + K(2, 3 + i) * X[2][j]);
+    }
+    const double id2 = kf_rcp(sym3_cofactors(S, c2));
+    KFPOS_UNROLL
+    for (int i = 0; i < 3; ++i) x[3 + i] = (c2[s3(i, 0)] * rhs[0] + c2[s3(i, 1)] * rhs[1] + c2[s3(i, 2)] * rhs[2]) * id2;
+    KFPOS_UNROLL
+    for (int i = 0; i < 3; ++i) x[i] = y1[i] - (X[i][0] * x[3] + X[i][1] * x[4] + X[i][2] * x[5]);
+}
+
+template <bool DIAG, bool RANGING, class SC>
+KFPOS_FN void iekf9_info(const double xhat[9], const double *binv, int binv_stride, SC &sc, const Params &pr,
+                         const Imu &imu, int max_steps, double tol, Iekf9Out &o) {
+    double p[3] = {xhat[0], xhat[1], xhat[2]}, acc[3] = {xhat[6], xhat[7], xhat[8]};
+    double ve[6] = {0, 0, 0, 0, 0, 0}; /* x_e - xhat_e = P_ee w */
+    double wl[6] = {0, 0, 0, 0, 0, 0};
+    double qd = 0.0, cost = 1e20;
+    KFPOS_UNROLL
+    for (int k = 0; k < 6; ++k) o.mrlast[k] = 0.0;
+    o.dlast[0] = o.dlast[1] = o.dlast[2] = 0.0;
+    o.gain_iters = 0;
+    for (int iter = 0; iter < max_steps; ++iter) {
+        double c = qd, m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0, u0 = 0, u1 = 0, u2 = 0;
+        if constexpr (RANGING) {
+            for_anchors<SC>(pr, [&](int a) {
+                const double dx = p[0] - pr.anchors[3 * a], dy = p[1] - pr.anchors[3 * a + 1],
+                             dz = p[2] - pr.anchors[3 * a + 2];
+                double d, invd;
+                kf_sqrt_rsqrt_sweep(dx * dx + dy * dy + dz * dz, d, invd);
+                const double w = sc.W(a), y = sc.R(a) - d; /* weight 0 = absent / dropped range (set_weights_iekf) */
+                const double yw = y * w;
+                c += y * yw;
+                const double gx = dx * invd, gy = dy * invd, gz = dz * invd;
+                u0 += gx * yw; u1 += gy * yw; u2 += gz * yw;
+                const double wx = w * gx, wy = w * gy, wz = w * gz;
+                m0 += wx * gx; m1 += wx * gy; m2 += wx * gz;
+                m3 += wy * gy; m4 += wy * gz; m5 += wz * gz;
+            });
+        }
+        const double m[6] = {m0, m1, m2, m3, m4, m5};
+        double u[6] = {u0 + (m0 * ve[0] + m1 * ve[1] + m2 * ve[2]), u1 + (m1 * ve[0] + m3 * ve[1] + m4 * ve[2]),
+                       u2 + (m2 * ve[0] + m4 * ve[1] + m5 * ve[2]), 0.0, 0.0, 0.0};
+        double ma[6] = {0, 0, 0, 0, 0, 0}; /* M_a = D Sigma^-1 D, symmetric {00,01,02,11,12,22} */
+        if (imu.has) {
+            const double ya[3] = {imu.acc[0] - acc[0], imu.acc[1] - acc[1], imu.acc[2] - acc[2]};
+            const double va[3] = {ya[0] + acc[0] * ve[3], ya[1] + acc[1] * ve[4], ya[2] + acc[2] * ve[5]};
+            if constexpr (DIAG) {
+                const double wd[3] = {imu.wi[0], imu.wi[3], imu.wi[5]};
+                KFPOS_UNROLL
+                for (int i = 0; i < 3; ++i) {
+                    const double wy = wd[i] * ya[i];
+                    c += ya[i] * wy;
+                    u[3 + i] = acc[i] * (wd[i] * va[i]);
+                }
+                ma[0] = acc[0] * acc[0] * wd[0]; ma[3] = acc[1] * acc[1] * wd[1]; ma[5] = acc[2] * acc[2] * wd[2];
+            } else {
+                const double wm[3][3] = {{imu.wi[0], imu.wi[1], imu.wi[2]},
+                                         {imu.wi[1], imu.wi[3], imu.wi[4]},
+                                         {imu.wi[2], imu.wi[4], imu.wi[5]}};
+                KFPOS_UNROLL
+                for (int i = 0; i < 3; ++i) {
+                    const double wy = wm[i][0] * ya[0] + wm[i][1] * ya[1] + wm[i][2] * ya[2];
+                    c += ya[i] * wy;
+                    u[3 + i] = acc[i] * (wm[i][0] * va[0] + wm[i][1] * va[1] + wm[i][2] * va[2]);
+                }
+                ma[0] = acc[0] * acc[0] * wm[0][0]; ma[1] = acc[0] * acc[1] * wm[0][1]; ma[2] = acc[0] * acc[2] * wm[0][2];
+                ma[3] = acc[1] * acc[1] * wm[1][1]; ma[4] = acc[1] * acc[2] * wm[1][2]; ma[5] = acc[2] * acc[2] * wm[2][2];
+            }
+        }
+        if (rel_change_below(cost, c, tol)) break; /* KalmanFilterTOAIMU.cpp:316 */
+        cost = c;
+        KFPOS_UNROLL
+        for (int k = 0; k < 6; ++k) o.mrlast[k] = m[k];
+        o.dlast[0] = acc[0]; o.dlast[1] = acc[1]; o.dlast[2] = acc[2];
+
+        /* (B^-1 + M) v = u; B^-1 is read back from where it was parked (LDS) rather than held in 42 registers */
+        Cov<6, true> K;
+        KFPOS_UNROLL
+        for (int k = 0; k < 21; ++k) K.a[k] = binv[k * binv_stride];
+        K(0, 0) += m[0]; K(0, 1) += m[1]; K(0, 2) += m[2]; K(1, 1) += m[3]; K(1, 2) += m[4]; K(2, 2) += m[5];
+        K(3, 3) += ma[0]; K(4, 4) += ma[3]; K(5, 5) += ma[5];
+        if constexpr (!DIAG) { K(3, 4) += ma[1]; K(3, 5) += ma[2]; K(4, 5) += ma[4]; }
+        sym6_solve(K, u, ve);
+        /* w = u - M v ; delta' pinv(P) delta = w . P_ee w = w . v */
+        wl[0] = u[0] - (m[0] * ve[0] + m[1] * ve[1] + m[2] * ve[2]);
+        wl[1] = u[1] - (m[1] * ve[0] + m[3] * ve[1] + m[4] * ve[2]);
+        wl[2] = u[2] - (m[2] * ve[0] + m[4] * ve[1] + m[5] * ve[2]);
+        /* (written out in full for the diagonal case too: a shorter form would round differently, and a tag must not
+         * see which wave-mates it has) */
+        wl[3] = u[3] - (ma[0] * ve[3] + ma[1] * ve[4] + ma[2] * ve[5]);
+        wl[4] = u[4] - (ma[1] * ve[3] + ma[3] * ve[4] + ma[4] * ve[5]);
+        wl[5] = u[5] - (ma[2] * ve[3] + ma[4] * ve[4] + ma[5] * ve[5]);
+        qd = 0.0;
+        KFPOS_UNROLL
+        for (int i = 0; i < 6; ++i) qd += wl[i] * ve[i];
+        KFPOS_UNROLL
+        for (int i = 0; i < 3; ++i) { p[i] = xhat[i] + ve[i]; acc[i] = xhat[6 + i] + ve[3 + i]; }
+        o.gain_iters++;
+    }
+    KFPOS_UNROLL
+    for (int k = 0; k < 6; ++k) o.w[k] = wl[k];
     o.cost = cost;
 }
 
@@ -355,10 +548,20 @@ KFPOS_FN void cov_update9(Cov<9, true> &P, const double mr[6], const double d[3]
 }
 
 /* KalmanFilterTOAIMU::estimatePositionKF (KalmanFilterTOAIMU.cpp:100-195) for one tag.
- * has_ranging = false is the IMU-only call of newIMUMeasurement (:91). */
-template <class SC>
-KFPOS_FN uint32_t step_imu9(Tag9 &tg, SC &sc, const Params &pr, double dt,
-                                   bool has_ranging, const Imu &imu) {
+ * RANGING = false is the IMU-only call of newIMUMeasurement (:91): its own instantiation (and kernel), so that a
+ * ranging epoch carries no code of it. */
+/* where the 45 covariance entries wait while the information-form iteration runs (it does not touch P), followed by
+ * the 21 entries of B^-1, which each iteration reads back, and the 6 of the accelerometer whitener (Imu::ci): element k
+ * at a[k * stride] -- LDS on the GPU ([72][lane]: 36 KB per wavefront), a stack array in the host emulation. The iteration then has the directly addressable half of
+ * the register file to itself instead of shuffling P and B^-1 through the accumulation registers. */
+struct CovPark9 {
+    double *a;
+    int stride;
+};
+
+template <bool RANGING, class SC>
+KFPOS_FN uint32_t step_imu9(Tag9 &tg, SC &sc, const Params &pr, double dt, const Imu &imu, const CovPark9 &park) {
+    constexpr bool has_ranging = RANGING;
     const int n_valid = has_ranging ? count_used(sc, pr, 0) : 0;
     if (!pr.use_init_pos && (isnan(tg.pos[0]) || isnan(tg.pos[1]))) { /* :121-122, z is not tested */
         if (!has_ranging) return 0;
@@ -380,19 +583,55 @@ KFPOS_FN uint32_t step_imu9(Tag9 &tg, SC &sc, const Params &pr, double dt,
         xhat[3 + k] = tg.vel[k] + dt * 0.0;
         xhat[6 + k] = 0.0;
     }
+    /* Prediction of the covariance, then B = P_ee and its inverse, BEFORE the ML solve: fewer values are alive here
+     * than behind it, and from here to the end of the iteration P waits in LDS (inversion and iteration work on B
+     * alone). In multi-epoch launches P is in registers at this point anyway; a single-epoch launch waits for its
+     * covariance loads here instead of behind the ML solve. */
+    predict9(tg.P, dt, pr.jolt);
+    Cov<6, true> B;
+    KFPOS_UNROLL
+    for (int i = 0; i < 6; ++i) {
+        KFPOS_UNROLL
+        for (int j = i; j < 6; ++j) B(i, j) = tg.P(e9(i), e9(j));
+    }
+    KFPOS_UNROLL
+    for (int k = 0; k < 45; ++k) park.a[k * park.stride] = tg.P.a[k];
+    double *binv = park.a + 45 * park.stride;
+    /* B safely invertible on every lane: the information-form iteration (the usual case); otherwise -- right after a
+     * fixed start, B is singular -- the (I + M B) form */
+    const bool invertible = sym6_inverse(B, binv, park.stride, INFO_FORM_MIN_PIVOT);
     Iekf9Out o;
-    iekf9_weights(xhat, sc, pr, has_ranging, n_valid, o); /* needs position + epoch only ... */
-    predict9(tg.P, dt, pr.jolt);                          /* ... so the covariance is first touched here */
+    iekf9_weights(xhat, sc, pr, has_ranging, n_valid, o); /* position + epoch only */
     /* The 9-state filter has no try/catch: the reference node aborts here. This core keeps the predicted
      * covariance and reports the tag instead. */
-    if (o.flags & ST_UPDATE_SKIPPED) return ST_UPDATE_SKIPPED;
-    /* exact zeros only: the whitener of a diagonal covariance produces them */
-    const bool diag = !imu.has || (imu.wi[1] == 0.0 && imu.wi[2] == 0.0 && imu.wi[4] == 0.0);
-    if (KFPOS_WAVE_ALL(diag)) iekf9<true>(xhat, tg.P, sc, pr, has_ranging, imu, 20, 1e-4, o);
-    else iekf9<false>(xhat, tg.P, sc, pr, has_ranging, imu, 20, 1e-4, o);
-    cov_update9(tg.P, o.mrlast, o.dlast, imu);
+    if (o.flags & ST_UPDATE_SKIPPED) {
+        KFPOS_UNROLL
+        for (int k = 0; k < 45; ++k) tg.P.a[k] = park.a[k * park.stride];
+        return ST_UPDATE_SKIPPED;
+    }
+    /* per lane, not per wavefront: a tag's arithmetic must not depend on its wave-mates (a wavefront whose lanes
+     * disagree runs both forms one after the other, each under its lanes' mask) */
+#ifdef KFPOS_EMU_STATS
+    kfpos_emu_stats[invertible ? 0 : 1]++;
+#endif
+    if (invertible) {
+        iekf9_info<false, RANGING>(xhat, binv, park.stride, sc, pr, imu, 20, 1e-4, o);
+        KFPOS_UNROLL
+        for (int k = 0; k < 45; ++k) tg.P.a[k] = park.a[k * park.stride];
+    } else {
+        KFPOS_UNROLL
+        for (int k = 0; k < 45; ++k) tg.P.a[k] = park.a[k * park.stride];
+        iekf9<false, RANGING>(xhat, tg.P, sc, pr, imu, 20, 1e-4, o);
+    }
     KFPOS_UNROLL
-    for (int k = 0; k < 3; ++k) { tg.pos[k] = o.x[k]; tg.vel[k] = o.x[3 + k]; } /* :189-194 */
+    for (int i = 0; i < 6; ++i) { /* x = xhat + P E' w: position and velocity are what the filter keeps (:189-194) */
+        double v = 0.0;
+        KFPOS_UNROLL
+        for (int k = 0; k < 6; ++k) v += tg.P(i, e9(k)) * o.w[k];
+        if (i < 3) tg.pos[i] = xhat[i] + v;
+        else tg.vel[i - 3] = xhat[i] + v;
+    }
+    cov_update9(tg.P, o.mrlast, o.dlast, imu);
     return pack_status(o.flags, o.gain_iters, o.ml_iters, -1);
 }
 

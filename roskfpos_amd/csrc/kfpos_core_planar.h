@@ -307,7 +307,7 @@ KFPOS_FN void iekf8(const double xhat[8], double z, const PM &P, Cov<8, true> &P
                 c += ymag * ymag / lt.mag[1];
             }
         }
-        if (fabs(cost - c) / cost < 1e-4) break; /* :473 */
+        if (rel_change_below(cost, c, 1e-4)) break; /* :473 */
         cost = c;
         o.mlast[0] = m0; o.mlast[1] = m1; o.mlast[2] = m3;
 

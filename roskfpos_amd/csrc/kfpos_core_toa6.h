@@ -175,7 +175,7 @@ struct Iekf6Out {
     double cost;
     int gain_iters, ml_iters;
     uint32_t flags;
-    bool pivot;       /* this step's 3x3 systems go through gauss3_solve (illconditioned()) */
+    int pivot;        /* this step's 3x3 systems go through gauss_solve (illconditioned()); an int: a trailing bool leaves padding bytes that the struct copies of the leave-one-out loop would move through scratch memory */
 };
 
 /* First half of kalmanStep3DIgnoreAnchor (KalmanFilterTOA.cpp:268-282): ML position -> observation
@@ -237,7 +237,7 @@ KFPOS_FN void iekf6(const double xhat_p[3], const Cov<6, SYMM> &P, SC &sc,
         const double m[6] = {m0, m1, m2, m3, m4, m5},
                      u[3] = {u0 - (m0 * dp[0] + m1 * dp[1] + m2 * dp[2]), u1 - (m1 * dp[0] + m3 * dp[1] + m4 * dp[2]),
                              u2 - (m2 * dp[0] + m4 * dp[1] + m5 * dp[2])};
-        if (fabs(cost - c) / cost < tol) break; /* KalmanFilterTOA.cpp:307 */
+        if (rel_change_below(cost, c, tol)) break; /* KalmanFilterTOA.cpp:307 */
         cost = c;
         KFPOS_UNROLL
         for (int k = 0; k < 6; ++k) o.mlast[k] = m[k];

@@ -186,8 +186,15 @@ __device__ inline StaticScratch<N> stage_epoch_lds_n(const KArgs &a, double *lds
     }
     return sc;
 }
+/* A wave-uniform epoch index the optimiser cannot see through: addresses derived from it are formed anew in every
+ * epoch (a few scalar instructions) instead of living as two dozen running row pointers across the whole epoch loop,
+ * where they exhaust the scalar registers and end up as spilled 64-bit per-lane addresses. */
+__device__ inline int opaque_uniform(int v) {
+    asm volatile("" : "+s"(v));
+    return v;
+}
 __device__ inline double epoch_dt(const KArgs &a, size_t t, int s) {
-    return a.n_steps > 1 ? a.dt_steps[s] : (a.dt ? a.dt[t] : a.dt_shared);
+    return a.n_steps > 1 ? a.dt_steps[s] : (a.dt ? a.dt[(uint32_t)t] : a.dt_shared);
 }
 
 /* a lane that sits a call out (dt < 0, or a dropped PX4Flow sample) still reports where its tag is: the trajectory /
@@ -399,21 +406,37 @@ __global__ __launch_bounds__(WAVE) void k_step_ml(const KArgs a) {
 }
 
 /* ------------------------------------------------------------------ 9-state step kernel */
+/* The acceleration sample is fetched one epoch ahead like the ranges. Its covariance is loaded and whitened ONCE per
+ * launch: a multi-epoch launch always has one covariance array for all its epochs (stride_cov = 0: a sensor with a
+ * fixed covariance); a trace with a covariance per epoch is replayed one epoch per launch (kfpos_run_trace_dev). */
 template <typename MREAL>
 struct RawImu {
-    MREAL acc[3], cov[9];
+    MREAL acc[3];
 };
 template <typename MREAL>
 __device__ inline void fetch_imu(const KArgs &a, size_t t, int s, RawImu<MREAL> &raw) {
     const MREAL *ap = (const MREAL *)a.accel + (size_t)s * a.stride_accel;
-    const MREAL *cp = (const MREAL *)a.cov + (size_t)s * a.stride_cov;
 #pragma unroll
     for (int k = 0; k < 3; ++k) raw.acc[k] = (ap + (size_t)k * a.T)[(uint32_t)t];
+}
+template <typename MREAL>
+__device__ inline void fetch_imu_cov(const KArgs &a, size_t t, int s, MREAL raw[9]) {
+    const MREAL *cp = (const MREAL *)a.cov + (size_t)s * a.stride_cov;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) raw.cov[k] = (cp + (size_t)k * a.T)[(uint32_t)t];
+    for (int k = 0; k < 9; ++k) raw[k] = (cp + (size_t)k * a.T)[(uint32_t)t];
+}
+template <typename MREAL>
+__device__ inline void latch_imu_cov(const KArgs &a, size_t T, uint32_t t32, const double cv[9]) {
+    strow<MREAL>(a.imu_cov, 0, T, t32, cv[0]);
+    strow<MREAL>(a.imu_cov, 1, T, t32, cv[3]);
+    strow<MREAL>(a.imu_cov, 2, T, t32, cv[4]);
+    strow<MREAL>(a.imu_cov, 3, T, t32, cv[6]);
+    strow<MREAL>(a.imu_cov, 4, T, t32, cv[7]);
+    strow<MREAL>(a.imu_cov, 5, T, t32, cv[8]);
 }
 
-template <typename REAL, typename MREAL, int AS>
+/* RANGING = false: the IMU-only call (MODE_IMU_ONLY), a kernel of its own */
+template <typename REAL, typename MREAL, int AS, bool RANGING = true>
 __global__ __launch_bounds__(WAVE) void k_step_imu9(const KArgs a) {
     extern __shared__ double lds[];
     const int lane = threadIdx.x;
@@ -422,10 +445,15 @@ __global__ __launch_bounds__(WAVE) void k_step_imu9(const KArgs a) {
     const size_t T = a.T;
     const uint32_t t32 = (uint32_t)t;
     const Params pr = make_params(a);
-    const bool has_ranging = a.mode != MODE_IMU_ONLY;
+    constexpr bool has_ranging = RANGING;
+    /* the next epoch's measurements are fetched one epoch AHEAD, behind the current epoch's arithmetic -- in the
+     * KFPOS_STORE_MIXED instantiation (the bench configuration); the other two (8-byte measurements: 22 more registers
+     * per lane across the whole step; 4-byte covariance: its rounding code) do not have the registers for that (they
+     * spill), so they fetch between two epochs instead */
+    constexpr bool AHEAD = sizeof(MREAL) == 4 && sizeof(REAL) == 8;
     const bool fresh_imu = a.mode != MODE_TOA;
     constexpr int NA = AS > 0 ? AS : 1;
-    if (a.n_steps == 1 && a.dt && a.dt[t] < 0.0) { /* no epoch / sample for this tag in this call */
+    if (a.n_steps == 1 && a.dt && a.dt[t32] < 0.0) { /* no epoch / sample for this tag in this call */
         skipped_lane(a, t, true);
         return;
     }
@@ -443,12 +471,19 @@ __global__ __launch_bounds__(WAVE) void k_step_imu9(const KArgs a) {
         tg.pos[k] = (a.pos + k * T)[t32];
         tg.vel[k] = (a.vel + k * T)[t32];
     }
-    uint32_t fl = a.flags[t];
+    uint32_t fl = a.flags[t32];
+    /* the covariance and B^-1 wait in LDS while the gain iteration runs, the accelerometer whitener for the whole
+     * launch: [72][lane], behind the generic kernel's epoch scratch */
+    const CovPark9 park{lds + ((AS == 0 && has_ranging) ? 3 * (size_t)a.A * WAVE : 0) + lane, WAVE};
     Imu imu;
     imu.has = false;
+    imu.ci = park.a + 66 * WAVE;
+    imu.ci_stride = WAVE;
     double cv[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    MREAL rawc[9];
     if (fresh_imu) {
         fetch_imu<MREAL>(a, t, 0, rawi);
+        fetch_imu_cov<MREAL>(a, t, 0, rawc);
     } else if (fl & FL_HAS_IMU) { /* re-fuse the latched sample (KalmanFilterTOAIMU.cpp:68-72) */
         imu.has = true;
 #pragma unroll
@@ -462,49 +497,51 @@ __global__ __launch_bounds__(WAVE) void k_step_imu9(const KArgs a) {
     }
 #pragma unroll
     for (int k = 0; k < 45; ++k) tg.P.a[k] = ldrow<REAL>(a.P, k, T, t32);
-    if (imu.has) imu_whitener(cv, imu.ci, imu.wi);
+    if (fresh_imu) { /* the covariance of the first (usually: of every) epoch of this launch */
+        imu.has = true;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) cv[k] = (double)rawc[k];
+        if (a.latch) latch_imu_cov<MREAL>(a, T, t32, cv);
+    }
+    if (imu.has) imu_whitener(cv, imu.ci, imu.ci_stride, imu.wi);
+
 
     uint32_t s = 0;
     for (int e = 0; e < a.n_steps; ++e) { /* the state stays in registers from epoch to epoch */
         const double dt = epoch_dt(a, t, e);
         if (fresh_imu) { /* fresh sample: newIMUMeasurement latches it (KalmanFilterTOAIMU.cpp:78-89) */
-            imu.has = true;
 #pragma unroll
             for (int k = 0; k < 3; ++k) imu.acc[k] = (double)rawi.acc[k];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) cv[k] = (double)rawi.cov[k];
-            imu_whitener(cv, imu.ci, imu.wi);
-            if (a.latch && e + 1 == a.n_steps) {
-#pragma unroll
-                for (int k = 0; k < 3; ++k) strow<MREAL>(a.imu_acc, k, T, t32, imu.acc[k]);
-                strow<MREAL>(a.imu_cov, 0, T, t32, cv[0]);
-                strow<MREAL>(a.imu_cov, 1, T, t32, cv[3]);
-                strow<MREAL>(a.imu_cov, 2, T, t32, cv[4]);
-                strow<MREAL>(a.imu_cov, 3, T, t32, cv[6]);
-                strow<MREAL>(a.imu_cov, 4, T, t32, cv[7]);
-                strow<MREAL>(a.imu_cov, 5, T, t32, cv[8]);
-                fl |= FL_HAS_IMU;
+            if (e + 1 < a.n_steps) {
+                if constexpr (AHEAD) fetch_imu<MREAL>(a, t, opaque_uniform(e + 1), rawi);
             }
-            if (e + 1 < a.n_steps) fetch_imu<MREAL>(a, t, e + 1, rawi);
         }
         if constexpr (AS > 0) {
             RegScratch<AS> sc;
             if (has_ranging) {
                 unpack_epoch<MREAL, AS>(raw, sc);
-                if (e + 1 < a.n_steps) fetch_epoch<MREAL, AS>(a, t, e + 1, raw);
+                if (e + 1 < a.n_steps) {
+                    if constexpr (AHEAD) fetch_epoch<MREAL, AS>(a, t, opaque_uniform(e + 1), raw);
+                }
             } else {
 #pragma unroll
                 for (int k = 0; k < AS; ++k) sc.r[k] = sc.e[k] = sc.w[k] = 0.0;
             }
-            s = step_imu9(tg, sc, pr, dt, has_ranging, imu);
+            s = step_imu9<RANGING>(tg, sc, pr, dt, imu, park);
+            if constexpr (!AHEAD) { /* 8-byte measurements: the next epoch is fetched when this one is over */
+                if (e + 1 < a.n_steps) {
+                    if (fresh_imu) fetch_imu<MREAL>(a, t, opaque_uniform(e + 1), rawi);
+                    if (has_ranging) fetch_epoch<MREAL, AS>(a, t, opaque_uniform(e + 1), raw);
+                }
+            }
         } else {
             Scratch sc{nullptr, nullptr, nullptr, WAVE};
-            if (has_ranging) sc = stage_epoch_lds<MREAL>(a, lds, lane, t, e);
-            s = step_imu9(tg, sc, pr, dt, has_ranging, imu);
+            if (has_ranging) sc = stage_epoch_lds<MREAL>(a, lds, lane, t, opaque_uniform(e));
+            s = step_imu9<RANGING>(tg, sc, pr, dt, imu, park);
         }
         if (a.traj) { /* the pose a per-epoch caller would have read back (getPose at timeLag 0) */
 #pragma unroll
-            for (int k = 0; k < 3; ++k) (a.traj + ((size_t)e * 3 + k) * T)[t32] = tg.pos[k];
+            for (int k = 0; k < 3; ++k) (a.traj + ((size_t)opaque_uniform(e) * 3 + k) * T)[t32] = tg.pos[k];
         }
         if constexpr (sizeof(REAL) == 4) { /* what n single-epoch launches would have kept in HBM */
             if (e + 1 < a.n_steps) {
@@ -514,6 +551,11 @@ __global__ __launch_bounds__(WAVE) void k_step_imu9(const KArgs a) {
         }
     }
 
+    if (fresh_imu && a.latch) { /* the last epoch's sample stays latched (lastImuMeasurement, KalmanFilterTOAIMU.cpp:78-89) */
+#pragma unroll
+        for (int k = 0; k < 3; ++k) strow<MREAL>(a.imu_acc, k, T, t32, imu.acc[k]);
+        fl |= FL_HAS_IMU;
+    }
     bool fin = true;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -528,8 +570,8 @@ __global__ __launch_bounds__(WAVE) void k_step_imu9(const KArgs a) {
     }
     const bool waiting = !a.use_init_pos && isnan(tg.pos[0]);
     if (!fin && !waiting) s |= ST_NONFINITE;
-    a.flags[t] = fl | FL_STARTED;
-    if (a.status) a.status[t] = s;
+    a.flags[t32] = fl | FL_STARTED;
+    if (a.status) a.status[t32] = s;
 }
 
 /* ------------------------------------------------------------------ 8-state planar step kernel */
@@ -901,6 +943,7 @@ namespace {
 
 size_t lds_bytes(const kfpos_handle *h) { return (size_t)3 * h->cfg.max_anchors * WAVE * sizeof(double); }
 size_t park_bytes() { return (size_t)36 * WAVE * sizeof(double); } /* 36 doubles per lane: CovSpill8 (planar), Pinv6 (6-state, full) */
+size_t park9_bytes() { return (size_t)72 * WAVE * sizeof(double); } /* CovPark9: the 9-state covariance and B^-1 during the gain iteration, the accelerometer whitener */
 
 void fill_args(const kfpos_handle *h, KArgs &a) {
     std::memcpy(a.anchors, h->anchors, sizeof(a.anchors));
@@ -981,7 +1024,8 @@ step_kernel_t toa6_kernel(int as, int heur) {
     return heur ? k_step_toa6<SYMM, REAL, MREAL, 0> : k_step_toa6<SYMM, REAL, MREAL, 0, 0>;
 }
 template <typename REAL, typename MREAL>
-step_kernel_t imu9_kernel(int as) {
+step_kernel_t imu9_kernel(int as, bool ranging) {
+    if (!ranging) return k_step_imu9<REAL, MREAL, 0, false>; /* no epoch: the anchor count plays no role */
     if (as == 8) return k_step_imu9<REAL, MREAL, 8>;
     return k_step_imu9<REAL, MREAL, 0>;
 }
@@ -1009,7 +1053,7 @@ step_kernel_t planar_kernel_st(int st, int as) {
          : st == KFPOS_STORE_MIXED ? planar_kernel<SENS, double, float>(as) : planar_kernel<SENS, double, double>(as);
 }
 
-step_kernel_t step_kernel(const kfpos_handle *h, bool sensor_call = false) {
+step_kernel_t step_kernel(const kfpos_handle *h, bool sensor_call = false, bool imu_only = false) {
     const int st = h->cfg.storage, as = (h->force_generic || sensor_call) ? 0 : static_anchors(h);
     if (h->cfg.model == KFPOS_MODEL_PLANAR)
         return (h->planar_sensors || sensor_call) ? planar_kernel_st<true>(st, as) : planar_kernel_st<false>(st, as);
@@ -1029,8 +1073,8 @@ step_kernel_t step_kernel(const kfpos_handle *h, bool sensor_call = false) {
              : st == KFPOS_STORE_MIXED ? toa6_kernel<true, double, float>(as, heur)
                                        : toa6_kernel<true, double, double>(as, heur);
     }
-    return st == KFPOS_STORE_F32 ? imu9_kernel<float, float>(as)
-         : st == KFPOS_STORE_MIXED ? imu9_kernel<double, float>(as) : imu9_kernel<double, double>(as);
+    return st == KFPOS_STORE_F32 ? imu9_kernel<float, float>(as, !imu_only)
+         : st == KFPOS_STORE_MIXED ? imu9_kernel<double, float>(as, !imu_only) : imu9_kernel<double, double>(as, !imu_only);
 }
 
 int launch_step(kfpos_handle *h, const KArgs &a, hipStream_t s) {
@@ -1049,7 +1093,8 @@ int launch_step(kfpos_handle *h, const KArgs &a, hipStream_t s) {
     size_t lds = (a.mode == MODE_IMU_ONLY || planar_sensor || !generic) ? 0 : lds_bytes(h);
     if (h->cfg.model == KFPOS_MODEL_PLANAR && (h->planar_sensors || planar_sensor)) lds += park_bytes();
     if (h->cfg.model == KFPOS_MODEL_TOA && h->full) lds += park_bytes(); /* Pinv6 of the non-symmetric layout */
-    hipLaunchKernelGGL(step_kernel(h, planar_sensor), dim3(blocks), dim3(WAVE), lds, s, a);
+    if (h->cfg.model == KFPOS_MODEL_TOA_IMU) lds += park9_bytes();
+    hipLaunchKernelGGL(step_kernel(h, planar_sensor, a.mode == MODE_IMU_ONLY && h->cfg.model == KFPOS_MODEL_TOA_IMU), dim3(blocks), dim3(WAVE), lds, s, a);
     HIPCHK(hipGetLastError());
     h->stepped = true;
     return KFPOS_OK;
@@ -1317,7 +1362,15 @@ int kfpos_create(const kfpos_config *cfg, kfpos_handle **out) {
         h->sm_d = (unsigned char *)dp;
     }
     const bool parks = cfg->model == KFPOS_MODEL_PLANAR || (cfg->model == KFPOS_MODEL_TOA && h->full);
-    if (lds_bytes(h) + (parks ? park_bytes() : 0) > 64 * 1024) {
+    if (cfg->model == KFPOS_MODEL_TOA_IMU && lds_bytes(h) + park9_bytes() > 64 * 1024) {
+        hipError_t e_ = hipFuncSetAttribute((const void *)step_kernel(h), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)(lds_bytes(h) + park9_bytes()));
+        if (e_ != hipSuccess) {
+            g_err = std::string("hipFuncSetAttribute: ") + hipGetErrorString(e_);
+            kfpos_destroy(h);
+            return KFPOS_ERR_HIP;
+        }
+    } else if (lds_bytes(h) + (parks ? park_bytes() : 0) > 64 * 1024) {
         hipError_t e_ = hipFuncSetAttribute((const void *)step_kernel(h), hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)(lds_bytes(h) + (h->full ? park_bytes() : 0)));
         if (e_ == hipSuccess && cfg->model == KFPOS_MODEL_PLANAR) { /* the instantiation ranging epochs switch to */
@@ -1533,7 +1586,8 @@ int kfpos_run_trace_dev(kfpos_handle *h, int32_t n_steps, const int32_t *range_m
     a.stride_accel = stride_accel;
     a.stride_cov = stride_cov;
     const size_t r = h->msz;
-    const int chunk = h->trace_chunk;
+    /* the kernels whiten the accelerometer covariance once per launch: a covariance per epoch means one epoch per launch */
+    const int chunk = (accel && stride_cov != 0) ? 1 : h->trace_chunk;
     /* Up to `chunk` epochs per launch: the kernel keeps every tag's state in registers across them, so
      * state traffic and launch boundaries are paid once per chunk instead of once per epoch. */
     for (int s0 = 0; s0 < n_steps; s0 += chunk) {

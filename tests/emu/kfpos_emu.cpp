@@ -45,6 +45,7 @@ struct kfe_bank {
     std::vector<Tag6<false>> t6f;
     std::vector<Tag9> t9;
     std::vector<Imu> imu;
+    std::vector<double> imu_ci; /* Imu::ci storage, 6 per tag (LDS on the GPU) */
     std::vector<uint32_t> flags;
     std::vector<double> ml_pos, ml_cov, ml_seed; /* model 2: standalone ML estimator */
     std::vector<Tag8> t8;                        /* model 3: planar filter */
@@ -106,9 +107,12 @@ kfe_bank *kfe_create(int model, int n_tags, int n_anchors, const double *anchors
     } else {
         b->t9.resize(n_tags);
         b->imu.resize(n_tags);
+        b->imu_ci.assign((size_t)6 * n_tags, 0.0);
         for (int t = 0; t < n_tags; ++t) {
             std::memset(&b->t9[t], 0, sizeof(Tag9));
             std::memset(&b->imu[t], 0, sizeof(Imu));
+            b->imu[t].ci = &b->imu_ci[(size_t)6 * t];
+            b->imu[t].ci_stride = 1;
             for (int k = 0; k < 3; ++k) b->t9[t].pos[k] = ip(t, k);
         }
     }
@@ -162,7 +166,8 @@ static uint32_t step_static(kfe_bank *b, int t, const int32_t *mm, const double 
     if (b->model == 2) return step_ml(&b->ml_pos[3 * t], &b->ml_cov[6 * t], sc, b->pr, &b->ml_seed[3 * t]);
     if (b->model == 0 && !b->full) return toa6_step(b->t6s[t], sc, b->pr, lag);
     if (b->model == 0) { double park[36]; return toa6_step(b->t6f[t], sc, b->pr, lag, park, 1); }
-    return step_imu9(b->t9[t], sc, b->pr, lag, true, b->imu[t]);
+    double park9[66];
+    return step_imu9<true>(b->t9[t], sc, b->pr, lag, b->imu[t], CovPark9{park9, 1});
 }
 
 /* compile-time anchor count over the strided scratch (the LDS-resident epoch of the 16-anchor kernels) */
@@ -173,7 +178,8 @@ static uint32_t step_static_lds(kfe_bank *b, int t, const int32_t *mm, const dou
     fill_scratch(b, mm, err, buf, sc);
     if (b->model == 0 && !b->full) return toa6_step(b->t6s[t], sc, b->pr, lag);
     if (b->model == 0) { double park[36]; return toa6_step(b->t6f[t], sc, b->pr, lag, park, 1); }
-    return step_imu9(b->t9[t], sc, b->pr, lag, true, b->imu[t]);
+    double park9[66];
+    return step_imu9<true>(b->t9[t], sc, b->pr, lag, b->imu[t], CovPark9{park9, 1});
 }
 
 extern "C" {
@@ -205,7 +211,7 @@ void kfe_step_toa(kfe_bank *b, const int32_t *range_mm, const double *err_est, c
             } else if (b->model == 2) st = step_ml(&b->ml_pos[3 * t], &b->ml_cov[6 * t], sc, b->pr, &b->ml_seed[3 * t]);
             else if (b->model == 0 && !b->full) st = toa6_step(b->t6s[t], sc, b->pr, lag);
             else if (b->model == 0) { double park[36]; st = toa6_step(b->t6f[t], sc, b->pr, lag, park, 1); }
-            else st = step_imu9(b->t9[t], sc, b->pr, lag, true, b->imu[t]);
+            else { double park9[66]; st = step_imu9<true>(b->t9[t], sc, b->pr, lag, b->imu[t], CovPark9{park9, 1}); }
         }
         b->flags[t] |= FL_STARTED;
         if (status) status[t] = st;
@@ -218,7 +224,7 @@ void kfe_latch_imu(kfe_bank *b, const double *accel, const double *cov) {
         Imu &im = b->imu[t];
         im.has = true;
         for (int k = 0; k < 3; ++k) im.acc[k] = accel[3 * t + k];
-        imu_whitener(cov + 9 * (size_t)t, im.ci, im.wi);
+        imu_whitener(cov + 9 * (size_t)t, im.ci, im.ci_stride, im.wi);
         b->flags[t] |= FL_HAS_IMU;
     }
 }
@@ -229,7 +235,8 @@ void kfe_step_imu(kfe_bank *b, const double *accel, const double *cov, const dou
     kfe_latch_imu(b, accel, cov);
     Scratch sc{nullptr, nullptr, nullptr, 1};
     for (int t = 0; t < b->T; ++t) {
-        uint32_t st = step_imu9(b->t9[t], sc, b->pr, dt[dt_len > 1 ? t : 0], false, b->imu[t]);
+        double park9[66];
+        uint32_t st = step_imu9<false>(b->t9[t], sc, b->pr, dt[dt_len > 1 ? t : 0], b->imu[t], CovPark9{park9, 1});
         b->flags[t] |= FL_STARTED;
         if (status) status[t] = st;
     }
