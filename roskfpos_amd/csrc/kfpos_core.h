@@ -326,6 +326,24 @@ struct StaticScratch : Scratch {
      * (156-452 bytes/lane measured); groups of 8 keep the live set of the 8-anchor kernels */
     static constexpr int CHUNK = N > 8 ? 8 : 0;
 };
+/* StaticScratch whose errorEstimations sit in LDS as the 4-byte values they arrived as (KFPOS_STORE_F32 / _MIXED): 20
+ * instead of 24 bytes per anchor and lane. At 16 anchors that is 20 KB per wavefront, so EIGHT workgroups fit the 160 KB
+ * of a CU instead of six, and BASELINE config 5 (4 096 wavefronts) runs in two full rounds of two wavefronts per SIMD
+ * instead of 2.67 ragged ones. */
+template <int N>
+struct StaticScratchF {
+    static constexpr int NA = N;
+    static constexpr int CHUNK = N > 8 ? 8 : 0;
+    static constexpr bool COOP = false;
+    double *r, *w;
+    float *e;
+    int stride;
+    KFPOS_HD double R(int a) const { return r[a * stride]; }
+    KFPOS_HD double E(int a) const { return (double)e[a * stride]; }
+    KFPOS_HD double W(int a) const { return w[a * stride]; }
+    KFPOS_HD void setW(int a, double v) { w[a * stride] = v; }
+    KFPOS_HD double Rdyn(int a) const { return r[a * stride]; }
+};
 /* Same view with the anchor count fixed at compile time: the epoch stays in registers, every anchor
  * loop unrolls, anchor coordinates become constant-offset scalar loads that the compiler batches. */
 template <int N>

@@ -163,18 +163,24 @@ KFPOS_FN uint64_t topn_mask(const double seed[3], SC &sc, const Params &pr, int 
     double p[3] = {seed[0], seed[1], seed[2]}, sse;
     set_weights_ml(sc, pr, 0ull);
     ml_estimate(p, sc, pr, 0, n_valid, sse);
+    /* residual^2 of every range at the ML position, once, into the working-weight slots (free between the two solves:
+     * the caller sets the weights of the kept set afterwards); then ndrop selection passes over those 16 numbers
+     * instead of ndrop passes that each recompute all the distances */
+    for_anchors<SC>(pr, [&](int a) {
+        const double dx = pr.anchors[3 * a] - p[0], dy = pr.anchors[3 * a + 1] - p[1], dz = pr.anchors[3 * a + 2] - p[2];
+        double d, invd;
+        kf_sqrt_rsqrt(dx * dx + dy * dy + dz * dz, d, invd);
+        const double rd = d - sc.R(a);
+        sc.setW(a, used(sc, a, 0) ? rd * rd : -1.0); /* an absent range never wins: every real residual^2 is >= 0 */
+    });
     uint64_t drop = 0;
     for (int k = 0; k < ndrop; ++k) {
         double worst = -1.0;
         int wi = -1;
         for_anchors<SC>(pr, [&](int a) {
-            const double dx = pr.anchors[3 * a] - p[0], dy = pr.anchors[3 * a + 1] - p[1],
-                         dz = pr.anchors[3 * a + 2] - p[2];
-            double d, invd;
-            kf_sqrt_rsqrt(dx * dx + dy * dy + dz * dz, d, invd);
-            const double rd = d - sc.R(a);
-            const bool take = used(sc, a, drop) && (rd * rd > worst);
-            worst = take ? rd * rd : worst;
+            const double r2 = sc.W(a);
+            const bool take = !((drop >> a) & 1ull) && (r2 > worst);
+            worst = take ? r2 : worst;
             wi = take ? a : wi;
         });
         if (wi < 0) break;

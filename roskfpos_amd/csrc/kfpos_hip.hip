@@ -193,6 +193,26 @@ __device__ inline int opaque_uniform(int v) {
     asm volatile("" : "+s"(v));
     return v;
 }
+/* the same with 4-byte errorEstimations kept as they are: LDS = r [N][lane] f64 | w [N][lane] f64 | e [N][lane] f32 */
+template <int N>
+__device__ inline StaticScratchF<N> stage_epoch_lds_nf(const KArgs &a, double *lds, int lane, size_t t, int s) {
+    StaticScratchF<N> sc;
+    sc.r = lds + lane;
+    sc.w = lds + (size_t)N * WAVE + lane;
+    sc.e = (float *)(lds + 2 * (size_t)N * WAVE) + lane;
+    sc.stride = WAVE;
+    RawEpoch<float, N> raw;
+    fetch_epoch<float, N>(a, t, s, raw);
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        sc.r[k * WAVE] = raw.mm[k] > 0 ? kf_mm_to_m(raw.mm[k]) : 0.0;
+        sc.e[k * WAVE] = raw.e[k];
+    }
+    return sc;
+}
+/* doubles of LDS the epoch of a compile-time-count kernel takes per workgroup */
+template <typename MREAL, int N>
+constexpr size_t static_epoch_doubles() { return sizeof(MREAL) == 4 ? (size_t)N * WAVE * 5 / 2 : (size_t)N * WAVE * 3; }
 __device__ inline double epoch_dt(const KArgs &a, size_t t, int s) {
     return a.n_steps > 1 ? a.dt_steps[s] : (a.dt ? a.dt[(uint32_t)t] : a.dt_shared);
 }
@@ -244,9 +264,12 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(1, 2))) vo
             unpack_epoch<MREAL, AS>(raw, sc);
             if (e + 1 < a.n_steps) fetch_epoch<MREAL, AS>(a, t, e + 1, raw); /* next epoch in flight */
             s = step_toa6<SYMM, HEUR>(tg, sc, pr, dt);
+        } else if constexpr (AS < 0 && sizeof(MREAL) == 4) { /* compile-time count, epoch in LDS, 4-byte errorEstimations */
+            StaticScratchF<-AS> sc = stage_epoch_lds_nf<-AS>(a, lds, lane, t, e);
+            s = step_toa6<SYMM, HEUR>(tg, sc, pr, dt, lds + static_epoch_doubles<MREAL, -AS>() + lane, WAVE);
         } else if constexpr (AS < 0) { /* compile-time count, epoch in LDS */
             StaticScratch<-AS> sc = stage_epoch_lds_n<MREAL, -AS>(a, lds, lane, t, e);
-            s = step_toa6<SYMM, HEUR>(tg, sc, pr, dt, lds + 3 * (size_t)(-AS) * WAVE + lane, WAVE);
+            s = step_toa6<SYMM, HEUR>(tg, sc, pr, dt, lds + static_epoch_doubles<MREAL, -AS>() + lane, WAVE);
         } else {
             Scratch sc = stage_epoch_lds<MREAL>(a, lds, lane, t, e);
             s = step_toa6<SYMM, HEUR>(tg, sc, pr, dt, lds + 3 * (size_t)a.A * WAVE + lane, WAVE);
@@ -1091,6 +1114,9 @@ int launch_step(kfpos_handle *h, const KArgs &a, hipStream_t s) {
                          (h->cfg.model == KFPOS_MODEL_PLANAR && h->planar_sensors);
     const bool planar_sensor = h->cfg.model == KFPOS_MODEL_PLANAR && a.mode != 0;
     size_t lds = (a.mode == MODE_IMU_ONLY || planar_sensor || !generic) ? 0 : lds_bytes(h);
+    /* the 6-state compile-time-count kernels keep 4-byte errorEstimations as they are: 20 bytes per anchor and lane */
+    if (lds && h->cfg.model == KFPOS_MODEL_TOA && !h->force_generic && static_anchors(h) != 0 && h->msz == 4)
+        lds = lds * 5 / 6;
     if (h->cfg.model == KFPOS_MODEL_PLANAR && (h->planar_sensors || planar_sensor)) lds += park_bytes();
     if (h->cfg.model == KFPOS_MODEL_TOA && h->full) lds += park_bytes(); /* Pinv6 of the non-symmetric layout */
     if (h->cfg.model == KFPOS_MODEL_TOA_IMU) lds += park9_bytes();
