@@ -16,7 +16,7 @@ namespace kfpos {
 template <class SC>
 KFPOS_FN void ml_sweep(const double p[3], const SC &sc, const Params &pr, uint64_t drop,
                               double &cw, double &sse, double g[3], double hs[6]) {
-    double cw_ = 0.0, sse_ = 0.0, g0 = 0.0, g1 = 0.0, g2 = 0.0;
+    double cw_ = 0.0, sse_ = 0.0, g0 = 0.0, g1 = 0.0, g2 = 0.0, c0s = 0.0;
     double h0 = 0.0, h1 = 0.0, h2 = 0.0, h3 = 0.0, h4 = 0.0, h5 = 0.0;
     for_anchors<SC>(pr, [&](int a) {
         /* branch-free: an absent / dropped range gets weight 0 (select, so a garbage errorEstimation of a
@@ -29,26 +29,30 @@ KFPOS_FN void ml_sweep(const double p[3], const SC &sc, const Params &pr, uint64
         const double dx = bx - p[0], dy = by - p[1], dz = bz - p[2];
         double d, invd;
         kf_sqrt_rsqrt_sweep(dx * dx + dy * dy + dz * dz, d, invd);
-        const double rd = r - d;
-        cw_ += rd * rd * w;
-        sse_ += on ? rd * rd : 0.0;
-        const double gi = rd * invd * w;
+        const double rd = r - d, rd2 = rd * rd;
+        cw_ += rd2 * w;
+        sse_ += on ? rd2 : 0.0;
+        /* with wi = w / d:  gradient weight (r - d) w / d,  Hessian terms w (1 - r/d) on the diagonal (summed once:
+         * the same number goes to all three entries) and w r / d^3 on the dyadic part */
+        const double wi = w * invd, gi = rd * wi, wq = r * wi;
         g0 += gi * dx;
         g1 += gi * dy;
         g2 += gi * dz;
-        const double q = r * invd;
-        const double c0 = w * (1.0 - q), c1 = w * q * invd * invd;
-        h0 += c0 + c1 * dx * dx;
-        h1 += c1 * dx * dy;
-        h2 += c1 * dx * dz;
-        h3 += c0 + c1 * dy * dy;
-        h4 += c1 * dy * dz;
-        h5 += c0 + c1 * dz * dz;
+        c0s += w - wq;
+        const double c1 = wq * (invd * invd);
+        const double tx = c1 * dx, ty = c1 * dy, tz = c1 * dz;
+        h0 += tx * dx;
+        h1 += tx * dy;
+        h2 += tx * dz;
+        h3 += ty * dy;
+        h4 += ty * dz;
+        h5 += tz * dz;
     });
     cw = group_sum(sc, cw_); sse = group_sum(sc, sse_);
     g[0] = group_sum(sc, g0); g[1] = group_sum(sc, g1); g[2] = group_sum(sc, g2);
-    hs[0] = group_sum(sc, h0); hs[1] = group_sum(sc, h1); hs[2] = group_sum(sc, h2);
-    hs[3] = group_sum(sc, h3); hs[4] = group_sum(sc, h4); hs[5] = group_sum(sc, h5);
+    const double c0 = group_sum(sc, c0s);
+    hs[0] = group_sum(sc, h0) + c0; hs[1] = group_sum(sc, h1); hs[2] = group_sum(sc, h2);
+    hs[3] = group_sum(sc, h3) + c0; hs[4] = group_sum(sc, h4); hs[5] = group_sum(sc, h5) + c0;
 }
 
 /* SSE only (estimationError at a given position) */

@@ -193,6 +193,13 @@ __device__ inline int opaque_uniform(int v) {
     asm volatile("" : "+s"(v));
     return v;
 }
+/* the same for the lane's tag index: its per-array 64-bit addresses are then formed where they are used instead of
+ * being carried (spilled) across the epoch loop */
+__device__ inline size_t opaque_lane(size_t t) {
+    uint32_t v = (uint32_t)t;
+    asm volatile("" : "+v"(v));
+    return v;
+}
 /* the same with 4-byte errorEstimations kept as they are: LDS = r [N][lane] f64 | w [N][lane] f64 | e [N][lane] f32 */
 template <int N>
 __device__ inline StaticScratchF<N> stage_epoch_lds_nf(const KArgs &a, double *lds, int lane, size_t t, int s) {
@@ -536,7 +543,7 @@ __global__ __launch_bounds__(WAVE) void k_step_imu9(const KArgs a) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) imu.acc[k] = (double)rawi.acc[k];
             if (e + 1 < a.n_steps) {
-                if constexpr (AHEAD) fetch_imu<MREAL>(a, t, opaque_uniform(e + 1), rawi);
+                if constexpr (AHEAD) fetch_imu<MREAL>(a, opaque_lane(t), opaque_uniform(e + 1), rawi);
             }
         }
         if constexpr (AS > 0) {
@@ -544,7 +551,7 @@ __global__ __launch_bounds__(WAVE) void k_step_imu9(const KArgs a) {
             if (has_ranging) {
                 unpack_epoch<MREAL, AS>(raw, sc);
                 if (e + 1 < a.n_steps) {
-                    if constexpr (AHEAD) fetch_epoch<MREAL, AS>(a, t, opaque_uniform(e + 1), raw);
+                    if constexpr (AHEAD) fetch_epoch<MREAL, AS>(a, opaque_lane(t), opaque_uniform(e + 1), raw);
                 }
             } else {
 #pragma unroll
@@ -553,8 +560,8 @@ __global__ __launch_bounds__(WAVE) void k_step_imu9(const KArgs a) {
             s = step_imu9<RANGING>(tg, sc, pr, dt, imu, park);
             if constexpr (!AHEAD) { /* 8-byte measurements: the next epoch is fetched when this one is over */
                 if (e + 1 < a.n_steps) {
-                    if (fresh_imu) fetch_imu<MREAL>(a, t, opaque_uniform(e + 1), rawi);
-                    if (has_ranging) fetch_epoch<MREAL, AS>(a, t, opaque_uniform(e + 1), raw);
+                    if (fresh_imu) fetch_imu<MREAL>(a, opaque_lane(t), opaque_uniform(e + 1), rawi);
+                    if (has_ranging) fetch_epoch<MREAL, AS>(a, opaque_lane(t), opaque_uniform(e + 1), raw);
                 }
             }
         } else {
