@@ -1,9 +1,15 @@
 #!/usr/bin/env python3
-"""HBM bytes per launch of the bench kernel from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE), corrected as
-/opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3 section) prescribes: the counters are in KB; on gfx950
-FETCH_SIZE reports half the bytes of wide coalesced reads and is doubled; WRITE_SIZE is exact.
+"""HBM bytes per launch of a step kernel from rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in SEPARATE passes),
+corrected as /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3 section) prescribes: the counters are in KB; on
+gfx950 FETCH_SIZE reports half the bytes of wide coalesced reads and is doubled; WRITE_SIZE is exact.
 
-    python tools/traffic_summary.py DIR_FETCH DIR_WRITE --match k_step_imu9 [--epochs-per-launch 25] > profiles/traffic_latest.json
+Two runs with different epochs-per-launch separate what a launch pays once (the per-tag state, read and written) from
+what it pays per epoch (measurements in, poses out):  bytes(E) = fixed + E * per_epoch.  The result is merged into
+profiles/traffic_latest.json under the kernel's name; bench.py rebuilds `roofline.traffic` from it for the launch length
+it actually timed and labels it as static.
+
+    python tools/traffic_summary.py --match k_step_imu9 --key "k_step_imu9<double,float,8>" --tags 65536 \
+        --run 25 DIR_FETCH DIR_WRITE --run 5 DIR_FETCH DIR_WRITE --note "..." --merge profiles/traffic_latest.json
 """
 import csv
 import glob
@@ -23,34 +29,52 @@ def mean_counter(d, counter, match):
     v = sorted(vals.values())
     if not v:
         raise SystemExit(f"no {counter} rows for kernels matching {match!r} under {d}")
-    # launches of the timed region dominate; drop a shorter tail launch if the launch sizes differ
+    # launches of the timed region dominate; drop shorter launches (warm-up, tails) when the launch sizes differ
     top = [x for x in v if x > 0.8 * v[-1]]
-    return sum(top) / len(top), len(top), len(v)
+    return sum(top) / len(top), len(top)
 
 
 def main():
-    a = [x for x in sys.argv[1:]]
-    match, epl = "k_step_imu9", 25
-    if "--match" in a:
-        i = a.index("--match"); match = a[i + 1]; del a[i:i + 2]
-    if "--epochs-per-launch" in a:
-        i = a.index("--epochs-per-launch"); epl = int(a[i + 1]); del a[i:i + 2]
-    dfetch, dwrite = a[0], a[1]
-    fkb, nf, _ = mean_counter(dfetch, "FETCH_SIZE", match)
-    wkb, nw, _ = mean_counter(dwrite, "WRITE_SIZE", match)
-    read, write = fkb * 1024 * 2, wkb * 1024
-    T = 65536
-    out = {
-        "hbm_bytes_per_launch": read + write,
-        "launch": f"{match}, {epl} epochs x {T} tags per launch (bench.py default)",
-        "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes "
-                  "(MI355X_MICROARCH.md, HBM section); counters are KB; FETCH_SIZE doubled (gfx950 correction), "
-                  "WRITE_SIZE exact; mean over the full-size launches of the run",
-        "raw": {"FETCH_SIZE_KB": fkb, "WRITE_SIZE_KB": wkb, "launches_averaged": [nf, nw]},
-        "corrected_bytes": {"read": read, "write": write},
-        "algorithmic_bytes_per_launch": 544 * T * epl,
-    }
-    json.dump(out, sys.stdout, indent=1)
+    a = sys.argv[1:]
+    opt = {"--match": None, "--key": None, "--tags": "65536", "--note": "", "--merge": None}
+    runs = []
+    i = 0
+    while i < len(a):
+        if a[i] == "--run":
+            runs.append((int(a[i + 1]), a[i + 2], a[i + 3]))
+            i += 4
+        elif a[i] in opt:
+            opt[a[i]] = a[i + 1]
+            i += 2
+        else:
+            raise SystemExit("unknown argument " + a[i])
+    match, key, T = opt["--match"], opt["--key"] or opt["--match"], int(opt["--tags"])
+    pts = []
+    for E, dfetch, dwrite in runs:
+        fkb, nf = mean_counter(dfetch, "FETCH_SIZE", match)
+        wkb, nw = mean_counter(dwrite, "WRITE_SIZE", match)
+        pts.append({"epochs_per_launch": E, "FETCH_SIZE_KB": fkb, "WRITE_SIZE_KB": wkb, "launches_averaged": [nf, nw],
+                    "read_bytes": fkb * 1024 * 2, "write_bytes": wkb * 1024, "bytes": fkb * 1024 * 2 + wkb * 1024})
+    if len(pts) >= 2:
+        p, q = pts[0], pts[-1]
+        per_epoch = (p["bytes"] - q["bytes"]) / (p["epochs_per_launch"] - q["epochs_per_launch"])
+        fixed = p["bytes"] - per_epoch * p["epochs_per_launch"]
+    else:
+        raise SystemExit("need two --run entries with different epochs per launch")
+    entry = {"bytes_per_launch_fixed": fixed, "bytes_per_epoch": per_epoch, "tags": T,
+             "fixed_bytes_per_tag": fixed / T, "per_epoch_bytes_per_tag": per_epoch / T,
+             "measured_with": opt["--note"],
+             "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes "
+                       "(MI355X_MICROARCH.md, HBM section); counters are KB; FETCH_SIZE doubled (gfx950 correction), "
+                       "WRITE_SIZE exact; mean over the full-size launches of each run; two launch lengths -> fixed + per-epoch",
+             "runs": pts}
+    out = {}
+    if opt["--merge"] and os.path.exists(opt["--merge"]):
+        out = json.load(open(opt["--merge"]))
+    out[key] = entry
+    if opt["--merge"]:
+        json.dump(out, open(opt["--merge"], "w"), indent=1)
+    json.dump({key: entry}, sys.stdout, indent=1)
     print()
 
 
