@@ -53,7 +53,7 @@ STORAGE_C3 = {"mixed": capi.STORE_MIXED, "f64": capi.STORE_F64, "f32": capi.STOR
     os.environ.get("KFPOS_BENCH_STORAGE", "mixed")]
 CONFIGS = {
     "c3": dict(model=capi.MODEL_TOA_IMU, storage=STORAGE_C3, bytes=544, scaling="weak", tags=65536,
-               kernel="k_step_imu9<double,float,8>", dtype="f64 arithmetic; f64 state and covariance, f32/int32 "
+               kernel="k_step_imu9<double,float,8,true>", dtype="f64 arithmetic; f64 state and covariance, f32/int32 "
                "measurements in HBM (KFPOS_STORE_MIXED)",
                workload="BASELINE configs[2]: 65536 tags x 8 anchors per GPU, UWB+IMU fused 9-state IEKF "
                         "(kfpos_toa_imu path), fp64 arithmetic, f32/int32 measurements, f64 covariance "
