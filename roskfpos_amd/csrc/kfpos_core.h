@@ -314,6 +314,7 @@ struct Scratch {
     KFPOS_HD double W(int a) const { return w[a * stride]; }
     KFPOS_HD void setW(int a, double v) { w[a * stride] = v; }
     KFPOS_HD double Rdyn(int a) const { return r[a * stride]; } /* a not a compile-time constant */
+    KFPOS_HD double Edyn(int a) const { return e[a * stride]; }
 };
 /* Scratch with the anchor count fixed at compile time but the epoch still outside the register file: the anchor
  * loops unroll (coordinates become batched constant-offset scalar loads, the LDS reads of a sweep are issued
@@ -343,6 +344,7 @@ struct StaticScratchF {
     KFPOS_HD double W(int a) const { return w[a * stride]; }
     KFPOS_HD void setW(int a, double v) { w[a * stride] = v; }
     KFPOS_HD double Rdyn(int a) const { return r[a * stride]; }
+    KFPOS_HD double Edyn(int a) const { return (double)e[a * stride]; }
 };
 /* Same view with the anchor count fixed at compile time: the epoch stays in registers, every anchor
  * loop unrolls, anchor coordinates become constant-offset scalar loads that the compiler batches. */
@@ -362,6 +364,12 @@ struct RegScratch {
         for (int k = 0; k < N; ++k) v = (k == a) ? r[k] : v;
         return v;
     }
+    KFPOS_HD double Edyn(int a) const {
+        double v = 1.0;
+        KFPOS_UNROLL
+        for (int k = 0; k < N; ++k) v = (k == a) ? e[k] : v;
+        return v;
+    }
 };
 /* One tag per GROUP OF 8 LANES, one anchor per lane. For small batches (a few thousand tags) the machine is mostly
  * empty and what bounds a step is the instruction chain of a single lane; here the anchor sweeps of a tag -- most of
@@ -378,6 +386,7 @@ struct CoopScratch {
     KFPOS_HD double W(int) const { return w; }
     KFPOS_HD void setW(int, double v) { w = v; }
     KFPOS_HD double Rdyn(int) const { return 0.0; } /* leave-one-out is not offered in this mode */
+    KFPOS_HD double Edyn(int) const { return 1.0; }
 };
 
 /* coordinates of anchor column a */

@@ -71,22 +71,58 @@ KFPOS_FN double ml_sse(const double p[3], const SC &sc, const Params &pr, uint64
     return group_sum(sc, sse);
 }
 
+/* Gradient and Hessian sums of the FIRST sweep of a solve (its cost and SSE are never looked at: the loop's first
+ * comparison is against the constant 1). The leave-one-out heuristic runs up to 65 solves from the same seed over
+ * subsets that differ by one range: their first sweeps are the sweep over all ranges minus one anchor's terms. */
+struct MlFirst {
+    double g[3], hs[6];
+};
+/* the terms anchor v (wave-uniform index) contributes to a sweep at p with weight w (0: none) and range r */
+template <class SC>
+KFPOS_FN void ml_terms_of(const double p[3], const Params &pr, int v, double r, double w, MlFirst &t) {
+    const double dx = pr.anchors[3 * v] - p[0], dy = pr.anchors[3 * v + 1] - p[1], dz = pr.anchors[3 * v + 2] - p[2];
+    double d, invd;
+    kf_sqrt_rsqrt_sweep(dx * dx + dy * dy + dz * dz, d, invd);
+    const double rd = r - d;
+    const double wi = w * invd, gi = rd * wi, wq = r * wi;
+    const double c0 = w - wq, c1 = wq * (invd * invd);
+    const double tx = c1 * dx, ty = c1 * dy, tz = c1 * dz;
+    t.g[0] = gi * dx; t.g[1] = gi * dy; t.g[2] = gi * dz;
+    t.hs[0] = tx * dx + c0; t.hs[1] = tx * dy; t.hs[2] = tx * dz;
+    t.hs[3] = ty * dy + c0; t.hs[4] = ty * dz; t.hs[5] = tz * dz + c0;
+}
+
 /* Gauss-Newton loop of MLLocation.cpp:164-225. p: seed in, estimate out. Requires sc.w = 1/e.
  * Returns the iteration count; sse_out = estimationError at the result. With n_used < 4 the
  * seed is returned untouched (MLLocation.cpp:158-161). The step p - Hs^-1 g equals the
  * reference's solve(Hs, Hs p - g). One sweep per pass yields the cost of the point just reached
  * and the gradient/Hessian for the next step (the reference evaluates them in two passes). */
+/* The leave-one-out heuristic hands in the gradient / Hessian sums of the first sweep (use_first, first) or asks for
+ * them (keep_first, first_out); flags and references rather than pointers, so that the sums stay in registers. */
 template <class SC>
-KFPOS_FN int ml_estimate(double p[3], const SC &sc, const Params &pr, uint64_t drop,
-                                int n_used, double &sse_out) {
+KFPOS_FN int ml_estimate(double p[3], const SC &sc, const Params &pr, uint64_t drop, int n_used, double &sse_out,
+                         bool use_first, const MlFirst &first, bool keep_first, MlFirst &first_out) {
     if (n_used < 4) {
         sse_out = (n_used == 0) ? -1.0 : ml_sse(p, sc, pr, drop);
         return 0;
     }
-    double cost = 1e20, newCost = 1.0, cw, sse, g[3], hs[6], c[6];
+    double cost = 1e20, newCost = 1.0, cw = 0.0, sse = 0.0, g[3], hs[6], c[6];
     int iter = 0;
     for (;;) {
-        ml_sweep(p, sc, pr, drop, cw, sse, g, hs);
+        if (use_first && iter == 0) {
+            KFPOS_UNROLL
+            for (int k = 0; k < 3; ++k) g[k] = first.g[k];
+            KFPOS_UNROLL
+            for (int k = 0; k < 6; ++k) hs[k] = first.hs[k];
+        } else {
+            ml_sweep(p, sc, pr, drop, cw, sse, g, hs);
+        }
+        if (keep_first && iter == 0) {
+            KFPOS_UNROLL
+            for (int k = 0; k < 3; ++k) first_out.g[k] = g[k];
+            KFPOS_UNROLL
+            for (int k = 0; k < 6; ++k) first_out.hs[k] = hs[k];
+        }
         if (iter > 0) newCost = cw;
         if (!((fabs(cost - newCost) / cost > 1e-3) && (iter < 10000))) break; /* MLLocation.cpp:168 */
         iter += 1;
@@ -98,6 +134,12 @@ KFPOS_FN int ml_estimate(double p[3], const SC &sc, const Params &pr, uint64_t d
     }
     sse_out = sse;
     return iter;
+}
+
+template <class SC>
+KFPOS_FN int ml_estimate(double p[3], const SC &sc, const Params &pr, uint64_t drop, int n_used, double &sse_out) {
+    MlFirst unused = {};
+    return ml_estimate(p, sc, pr, drop, n_used, sse_out, false, unused, false, unused);
 }
 
 /* covariance of the ML estimate, inv(J' diag(max(e, e_ML))^-1 J) (MLLocation.cpp:229-252);

@@ -183,11 +183,11 @@ struct Iekf6Out {
  * loads are still in flight. Leaves sc.w = 1/R. */
 template <class SC>
 KFPOS_FN void iekf6_weights(const double xhat_p[3], SC &sc, const Params &pr, uint64_t drop, int n_used,
-                            Iekf6Out &o) {
+                            Iekf6Out &o, bool use_first, const MlFirst &first, bool keep_first, MlFirst &first_out) {
     o.flags = (n_used < 4) ? ST_FEW_RANGES : 0u;
     double pml[3] = {xhat_p[0], xhat_p[1], xhat_p[2]}, e_ml;
     set_weights_ml(sc, pr, drop);
-    o.ml_iters = ml_estimate(pml, sc, pr, drop, n_used, e_ml);
+    o.ml_iters = ml_estimate(pml, sc, pr, drop, n_used, e_ml, use_first, first, keep_first, first_out);
     if (ml_covariance_throws(sc, pr, drop, n_used, e_ml)) o.flags |= ST_UPDATE_SKIPPED;
     if (isnan(pml[0]) || isnan(pml[1]) || isnan(pml[2])) {
         o.flags |= ST_ML_FALLBACK;
@@ -373,6 +373,7 @@ KFPOS_FN uint32_t step_toa6(Tag6<SYMM> &tg, SC &sc, const Params &pr_in, double 
      * once. v is uniform across the wavefront (anchor coordinates stay scalar loads) and there is ONE call
      * site of the solver, so the kernel carries a single inlined copy of it. */
     Iekf6Out o = {}, o_all = {}, o_best = {};
+    MlFirst first_all = {};
     Pinv6 pinv{false, park, park_stride};
     int ignored = -1;
     const int A = SC::NA > 0 ? SC::NA : pr.n_anchors;
@@ -399,7 +400,25 @@ KFPOS_FN uint32_t step_toa6(Tag6<SYMM> &tg, SC &sc, const Params &pr_in, double 
         if (!active) continue;
         const uint64_t mask = (last || v < 0) ? drop : (drop | (1ull << v));
         const int n_use = (last || v < 0) ? n_valid : n_valid - 1;
-        iekf6_weights(xhat_p, sc, pr, mask, n_use, o);
+        /* every solve of the heuristic starts at the same seed: the all-ranges solve (v = -1) leaves the gradient /
+         * Hessian sums of its first sweep, a leave-one-out solve subtracts anchor v's terms from them instead of
+         * sweeping the other ranges again (one anchor instead of A per solve). Still ONE call site of the solver. */
+        MlFirst f = {};
+        bool use_first = false, keep_first = false;
+        if constexpr (HEUR == 2 && SYMM && !SC::COOP) { /* (the non-symmetric layout's kernels have no register to spare) */
+            if (v < 0) {
+                keep_first = true;
+            } else if (!last) {
+                MlFirst t;
+                ml_terms_of<SC>(xhat_p, pr, v, ra, kf_rcp(sc.Edyn(v)), t);
+                KFPOS_UNROLL
+                for (int k = 0; k < 3; ++k) f.g[k] = first_all.g[k] - t.g[k];
+                KFPOS_UNROLL
+                for (int k = 0; k < 6; ++k) f.hs[k] = first_all.hs[k] - t.hs[k];
+                use_first = true;
+            }
+        }
+        iekf6_weights(xhat_p, sc, pr, mask, n_use, o, use_first, f, keep_first, first_all);
         if (!predicted) { /* after the first ML solve: the covariance loads have landed by now */
             predict6(tg.P, dt, pr.accel_noise);
             predicted = true;
