@@ -183,8 +183,11 @@ int kfpos_step_toa_imu(kfpos_handle *h, const int32_t *range_mm, const void *err
  * kfpos_step_toa. Other models: the reference's empty virtuals, returns KFPOS_OK and status 0. */
 int kfpos_step_sensor(kfpos_handle *h, int32_t kind, const double *data,
                       const double *dt, int32_t dt_len, uint32_t *status);
-/* mUWBtagZ of every tag (n_tags doubles): the configured height, or the ML initialisation's z */
+/* mUWBtagZ of every tag (n_tags doubles): the configured height, or the ML initialisation's z. kfpos_set_height puts
+ * it back when a checkpoint is restored (with useFixedHeight = 0 the 3-D ML initialisation replaced the configured
+ * value, KalmanFilter.cpp:252-258). KFPOS_MODEL_PLANAR only. */
 int kfpos_get_height(kfpos_handle *h, double *z);
+int kfpos_set_height(kfpos_handle *h, const double *z);
 
 /* getPose for every tag (KalmanFilterTOA.cpp:438-473, KalmanFilterTOAIMU.cpp:476-510): predict-only
  * extrapolation by dt_ahead, filter state untouched. pos n_tags x 3, cov3x3 n_tags x 9 (position block of
@@ -216,7 +219,9 @@ int kfpos_set_state(kfpos_handle *h, const double *x, const double *P, const uin
  * 9-state: 12 = linearAcceleration[3] + its covariance 3x3 row-major (KalmanFilterTOAIMU.h:58-59); planar: 15 =
  * PX4Flow {vx, vy, gyroz, covarianceVelocity, covarianceGyroZ}, IMU {ax, ay, angularVelocityZ,
  * covarianceAccelerationXY[4], covarianceAngularVelocityZ}, magnetometer {angle, covarianceMag}
- * (sensor_types.h:32-60); other models: 0, both calls are no-ops. Which samples are live is in the flags word. */
+ * (sensor_types.h:32-60); ALGORITHM_ML: 3 = _previousEstimation, the seed of every solve (MLLocation.cpp:3-22);
+ * 6-state filter: 0, both calls are no-ops. Which samples are live is in the flags word. A complete checkpoint of a
+ * handle = kfpos_get_state + flags, kfpos_get_latch and, for the planar filter, kfpos_get_height. */
 int kfpos_latch_dim(const kfpos_handle *h);
 int kfpos_get_latch(kfpos_handle *h, double *latch);
 int kfpos_set_latch(kfpos_handle *h, const double *latch);

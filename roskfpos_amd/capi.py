@@ -31,7 +31,7 @@ EXPORTS = [
     "kfpos_state_dim", "kfpos_get_state", "kfpos_set_state", "kfpos_step_toa_dev", "kfpos_step_imu_dev",
     "kfpos_step_toa_imu_dev", "kfpos_get_pose_dev", "kfpos_run_trace_dev", "kfpos_last_error",
     "kfpos_strerror", "kfpos_version", "kfpos_timing_begin", "kfpos_timing_end",
-    "kfpos_set_planar", "kfpos_step_sensor", "kfpos_step_sensor_dev", "kfpos_get_height",
+    "kfpos_set_planar", "kfpos_step_sensor", "kfpos_step_sensor_dev", "kfpos_get_height", "kfpos_set_height",
     "kfpos_latch_dim", "kfpos_get_latch", "kfpos_set_latch",
     "kfpos_slot_count", "kfpos_slot_acquire", "kfpos_slot_submit", "kfpos_slot_wait",
 ]
@@ -110,6 +110,7 @@ def load():
     L.kfpos_step_sensor.argtypes = [vp, i32, vp, vp, i32, vp]
     L.kfpos_step_sensor_dev.argtypes = [vp, i32, vp, vp, f64, vp, vp]
     L.kfpos_get_height.argtypes = [vp, vp]
+    L.kfpos_set_height.argtypes = [vp, vp]
     L.kfpos_latch_dim.argtypes = [vp]
     L.kfpos_get_latch.argtypes = [vp, vp]
     L.kfpos_set_latch.argtypes = [vp, vp]
@@ -253,6 +254,11 @@ class KfposBank:
         z = np.zeros(self.T)
         self._chk(self.lib.kfpos_get_height(self._h, z.ctypes.data))
         return z
+
+    def set_height(self, z):
+        a = np.ascontiguousarray(z, dtype=np.float64)
+        assert a.shape == (self.T,)
+        self._chk(self.lib.kfpos_set_height(self._h, a.ctypes.data))
 
     def get_pose(self, dt_ahead=0.0):
         pos, cov, vel = np.zeros((self.T, 3)), np.zeros((self.T, 9)), np.zeros((self.T, 3))

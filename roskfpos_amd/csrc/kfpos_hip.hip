@@ -1960,6 +1960,15 @@ int kfpos_get_height(kfpos_handle *h, double *z) {
     return KFPOS_OK;
 }
 
+int kfpos_set_height(kfpos_handle *h, const double *z) {
+    g_err.clear();
+    if (!h || !z) return KFPOS_ERR_ARG;
+    if (h->cfg.model != KFPOS_MODEL_PLANAR) return KFPOS_ERR_MODEL;
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(h->d_pos + 2 * (size_t)h->cfg.n_tags, z, sizeof(double) * h->cfg.n_tags, hipMemcpyHostToDevice));
+    return KFPOS_OK;
+}
+
 int kfpos_step_toa_imu(kfpos_handle *h, const int32_t *range_mm, const void *err_est, const void *accel,
                        const void *cov, const double *dt, int32_t dt_len, uint32_t *status) {
     g_err.clear();
@@ -2190,7 +2199,7 @@ int kfpos_set_state(kfpos_handle *h, const double *x, const double *P, const uin
 int kfpos_latch_dim(const kfpos_handle *h) {
     g_err.clear();
     if (!h) return 0;
-    return h->cfg.model == KFPOS_MODEL_TOA_IMU ? 12 : (h->cfg.model == KFPOS_MODEL_PLANAR ? LATCH_ROWS : 0);
+    return h->cfg.model == KFPOS_MODEL_TOA_IMU ? 12 : (h->cfg.model == KFPOS_MODEL_PLANAR ? LATCH_ROWS : (h->cfg.model == KFPOS_MODEL_ML ? 3 : 0));
 }
 
 int kfpos_get_latch(kfpos_handle *h, double *latch) {
@@ -2203,6 +2212,7 @@ int kfpos_get_latch(kfpos_handle *h, double *latch) {
     stage_reset(h);
     const size_t T = h->cfg.n_tags;
     if (L == LATCH_ROWS) return stage_out(h, latch, h->d_latch, LATCH_ROWS);
+    if (L == 3) return stage_out(h, latch, h->d_vel, 3); /* ALGORITHM_ML: _previousEstimation, the seed of every solve */
     /* 9-state: acceleration [3][T] and the lower triangle {00,10,11,20,21,22} [6][T], kfpos_real */
     std::vector<unsigned char> a(3 * T * h->msz), c(6 * T * h->msz);
     HIPCHK(hipMemcpy(a.data(), h->d_imu_acc, a.size(), hipMemcpyDeviceToHost));
@@ -2229,6 +2239,7 @@ int kfpos_set_latch(kfpos_handle *h, const double *latch) {
     stage_reset(h);
     const size_t T = h->cfg.n_tags;
     if (L == LATCH_ROWS) return stage_in(h, h->d_latch, latch, LATCH_ROWS, sizeof(double));
+    if (L == 3) return stage_in(h, h->d_vel, latch, 3, sizeof(double));
     std::vector<unsigned char> a(3 * T * h->msz), c(6 * T * h->msz);
     auto wr = [&](std::vector<unsigned char> &b, size_t k, double v) {
         if (h->msz == 4) ((float *)b.data())[k] = (float)v;

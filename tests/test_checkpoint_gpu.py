@@ -63,3 +63,49 @@ def test_planar_checkpoint_carries_all_latches():
     xb, Pb = b.get_state()
     np.testing.assert_array_equal(xa, xb)
     np.testing.assert_array_equal(Pa, Pb)
+
+
+def test_planar_checkpoint_with_estimated_height_and_ml_initialisation():
+    """useFixedHeight = 0 and no start position: the 3-D ML initialisation sets each tag's working height
+    (KalmanFilter.cpp:252-258), which is part of the checkpoint (kfpos_get_height / kfpos_set_height)."""
+    T = 70
+    w = Workload(T, 8)
+    cfg = dict(CFG, use_fixed_height=0)
+    a = PlanarGpu(w, cfg, None)
+    run_trace([a], w, 12, ("imu", "compass"))
+    x, P, fl = a.b.get_state()
+    latch, z = a.b.get_latch(), a.get_height()
+    assert np.ptp(z) > 0.01                      # estimated heights, not the configured constant
+    b = PlanarGpu(w, cfg, None)
+    b.b.set_state(x, P, fl)
+    b.b.set_latch(latch)
+    assert not np.array_equal(b.get_height(), z)  # a fresh handle starts at the configured height ...
+    b.b.set_height(z)                             # ... the checkpoint carries the estimated one
+    np.testing.assert_array_equal(b.get_height(), z)
+    for s in range(12, 22):
+        r, dt = w.ranges_mm(s), w.dt_of(s)
+        np.testing.assert_array_equal(a.step_toa(r, w.err_est(), dt), b.step_toa(r, w.err_est(), dt))
+    xa, Pa = a.get_state()
+    xb, Pb = b.get_state()
+    np.testing.assert_array_equal(xa, xb)
+    np.testing.assert_array_equal(Pa, Pb)
+
+
+def test_ml_estimator_checkpoint_carries_the_seed():
+    from roskfpos_amd import capi
+    T = 40
+    w = Workload(T, 8)
+    seeds = w.init_positions() + 0.3
+    a = capi.KfposBank(capi.MODEL_ML, T, w.anchors, init_pos=seeds)
+    for s in range(3):
+        a.step_toa(w.ranges_mm(s), w.err_est(), 0.05)
+    x, P, fl = a.get_state()
+    seed = a.get_latch()
+    np.testing.assert_array_equal(seed, seeds)
+    b = capi.KfposBank(capi.MODEL_ML, T, w.anchors, init_pos=np.zeros((T, 3)) + 1.0)   # other seeds
+    b.set_state(x, P, fl)
+    b.set_latch(seed)
+    for s in range(3, 6):
+        np.testing.assert_array_equal(a.step_toa(w.ranges_mm(s), w.err_est(), 0.05),
+                                      b.step_toa(w.ranges_mm(s), w.err_est(), 0.05))
+    np.testing.assert_array_equal(a.get_state()[0], b.get_state()[0])
