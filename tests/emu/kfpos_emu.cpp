@@ -290,10 +290,33 @@ void kfe_get_height(const kfe_bank *b, double *z) {
     for (int t = 0; t < b->T; ++t) z[t] = b->t8[t].z;
 }
 
+/* candidate 6-byte encodings of a covariance entry (study only: tests/cov_encoding_study.py) */
+static double enc_f32_bf16(double v) { /* f32 value + bf16 residual */
+    const float hi = (float)v;
+    float lo = (float)(v - (double)hi);
+    uint32_t u;
+    std::memcpy(&u, &lo, 4);
+    u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u; /* round to nearest even on the upper 16 bits */
+    std::memcpy(&lo, &u, 4);
+    return (double)hi + (double)lo;
+}
+static double enc_f48(double v) { /* the upper 6 bytes of the double: 36 mantissa bits, rounded */
+    uint64_t u;
+    std::memcpy(&u, &v, 8);
+    u = (u + 0x7FFFull + ((u >> 16) & 1ull)) & ~0xFFFFull;
+    std::memcpy(&v, &u, 8);
+    return v;
+}
+
 /* Emulate KFPOS_STORE_F32: what the step kernels keep in HBM between epochs is rounded to float
- * (covariance when what&1, velocity when what&2); positions always stay double. */
+ * (covariance when what&1, velocity when what&2); positions always stay double. what&4 / what&8: the covariance
+ * through the f32 + bf16 / 48-bit encodings above instead. */
 void kfe_round_storage(kfe_bank *b, int what) {
     for (int t = 0; t < b->T; ++t) {
+        if (b->model == 1 && (what & 12)) {
+            for (double &v : b->t9[t].P.a) v = (what & 4) ? enc_f32_bf16(v) : enc_f48(v);
+            continue;
+        }
         if (b->model == 1) {
             if (what & 1) for (double &v : b->t9[t].P.a) v = (double)(float)v;
             if (what & 2) for (double &v : b->t9[t].vel) v = (double)(float)v;
