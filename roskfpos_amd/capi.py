@@ -85,44 +85,51 @@ def load():
         pass
     L = C.CDLL(LIB_PATH)
     vp, i32, f64 = C.c_void_p, C.c_int32, C.c_double
-    L.kfpos_create.argtypes = [C.POINTER(_Config), C.POINTER(vp)]
-    L.kfpos_destroy.argtypes = [vp]
-    L.kfpos_init.argtypes = [vp]
-    L.kfpos_set_anchors.argtypes = [vp, vp, vp, i32]
-    L.kfpos_set_init_positions.argtypes = [vp, vp]
-    L.kfpos_real_size.argtypes = [vp]
-    L.kfpos_state_dim.argtypes = [vp]
-    L.kfpos_step_toa.argtypes = [vp, vp, vp, vp, i32, vp]
-    L.kfpos_step_imu.argtypes = [vp, vp, vp, vp, i32, vp]
-    L.kfpos_step_toa_imu.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp]
-    L.kfpos_get_pose.argtypes = [vp, f64, vp, vp, vp, vp]
-    L.kfpos_get_pose_each.argtypes = [vp, vp, vp, vp, vp, vp]
-    L.kfpos_get_predicted.argtypes = [vp, vp, i32, vp, vp, vp]
-    L.kfpos_get_state.argtypes = [vp, vp, vp, vp]
-    L.kfpos_set_state.argtypes = [vp, vp, vp, vp]
-    L.kfpos_step_toa_dev.argtypes = [vp, vp, vp, vp, f64, vp, vp]
-    L.kfpos_step_imu_dev.argtypes = [vp, vp, vp, vp, f64, vp, vp]
-    L.kfpos_step_toa_imu_dev.argtypes = [vp, vp, vp, vp, vp, i32, vp, f64, vp, vp]
-    L.kfpos_get_pose_dev.argtypes = [vp, f64, vp, vp, vp, vp, vp]
+
+    def sig(name, argtypes):
+        # an A/B build from an older revision (KFPOS_LIB_PATH) may lack the newest entry points: calling one then
+        # fails with AttributeError, everything else works
+        if hasattr(L, name):
+            getattr(L, name).argtypes = argtypes
+
+    sig("kfpos_create", [C.POINTER(_Config), C.POINTER(vp)])
+    sig("kfpos_destroy", [vp])
+    sig("kfpos_init", [vp])
+    sig("kfpos_set_anchors", [vp, vp, vp, i32])
+    sig("kfpos_set_init_positions", [vp, vp])
+    sig("kfpos_real_size", [vp])
+    sig("kfpos_state_dim", [vp])
+    sig("kfpos_step_toa", [vp, vp, vp, vp, i32, vp])
+    sig("kfpos_step_imu", [vp, vp, vp, vp, i32, vp])
+    sig("kfpos_step_toa_imu", [vp, vp, vp, vp, vp, vp, i32, vp])
+    sig("kfpos_get_pose", [vp, f64, vp, vp, vp, vp])
+    sig("kfpos_get_pose_each", [vp, vp, vp, vp, vp, vp])
+    sig("kfpos_get_predicted", [vp, vp, i32, vp, vp, vp])
+    sig("kfpos_get_state", [vp, vp, vp, vp])
+    sig("kfpos_set_state", [vp, vp, vp, vp])
+    sig("kfpos_step_toa_dev", [vp, vp, vp, vp, f64, vp, vp])
+    sig("kfpos_step_imu_dev", [vp, vp, vp, vp, f64, vp, vp])
+    sig("kfpos_step_toa_imu_dev", [vp, vp, vp, vp, vp, i32, vp, f64, vp, vp])
+    sig("kfpos_get_pose_dev", [vp, f64, vp, vp, vp, vp, vp])
     L.kfpos_run_trace_dev.argtypes = [vp, i32, vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, vp, C.c_int64,
                                       vp, vp, vp, vp]
-    L.kfpos_set_planar.argtypes = [vp, C.POINTER(PlanarConfig)]
-    L.kfpos_step_sensor.argtypes = [vp, i32, vp, vp, i32, vp]
-    L.kfpos_step_sensor_dev.argtypes = [vp, i32, vp, vp, f64, vp, vp]
-    L.kfpos_get_height.argtypes = [vp, vp]
-    L.kfpos_set_height.argtypes = [vp, vp]
-    L.kfpos_latch_dim.argtypes = [vp]
-    L.kfpos_get_latch.argtypes = [vp, vp]
-    L.kfpos_set_latch.argtypes = [vp, vp]
-    L.kfpos_slot_count.argtypes = [vp]
-    L.kfpos_slot_acquire.argtypes = [vp, i32, C.POINTER(_EpochSlot)]
-    L.kfpos_slot_submit.argtypes = [vp, i32, i32, f64]
-    L.kfpos_slot_wait.argtypes = [vp, i32]
-    L.kfpos_timing_begin.argtypes = [vp, vp]
-    L.kfpos_timing_end.argtypes = [vp, vp, C.POINTER(C.c_float)]
+    sig("kfpos_set_planar", [vp, C.POINTER(PlanarConfig)])
+    sig("kfpos_step_sensor", [vp, i32, vp, vp, i32, vp])
+    sig("kfpos_step_sensor_dev", [vp, i32, vp, vp, f64, vp, vp])
+    sig("kfpos_get_height", [vp, vp])
+    sig("kfpos_set_height", [vp, vp])
+    sig("kfpos_latch_dim", [vp])
+    sig("kfpos_get_latch", [vp, vp])
+    sig("kfpos_set_latch", [vp, vp])
+    sig("kfpos_slot_count", [vp])
+    sig("kfpos_slot_acquire", [vp, i32, C.POINTER(_EpochSlot)])
+    sig("kfpos_slot_submit", [vp, i32, i32, f64])
+    sig("kfpos_slot_wait", [vp, i32])
+    sig("kfpos_timing_begin", [vp, vp])
+    sig("kfpos_timing_end", [vp, vp, C.POINTER(C.c_float)])
     L.kfpos_last_error.restype = C.c_char_p
     L.kfpos_strerror.restype = C.c_char_p
-    L.kfpos_strerror.argtypes = [C.c_int]
+    sig("kfpos_strerror", [C.c_int])
     _lib = L
     return L
 

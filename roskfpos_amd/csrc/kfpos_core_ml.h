@@ -50,9 +50,9 @@ KFPOS_FN void ml_sweep(const double p[3], const SC &sc, const Params &pr, uint64
     });
     cw = group_sum(sc, cw_); sse = group_sum(sc, sse_);
     g[0] = group_sum(sc, g0); g[1] = group_sum(sc, g1); g[2] = group_sum(sc, g2);
-    const double c0 = group_sum(sc, c0s);
-    hs[0] = group_sum(sc, h0) + c0; hs[1] = group_sum(sc, h1); hs[2] = group_sum(sc, h2);
-    hs[3] = group_sum(sc, h3) + c0; hs[4] = group_sum(sc, h4); hs[5] = group_sum(sc, h5) + c0;
+    /* (the diagonal term joins the partial sums before they are combined: no extra exchange in the 8-lanes-per-tag mode) */
+    hs[0] = group_sum(sc, h0 + c0s); hs[1] = group_sum(sc, h1); hs[2] = group_sum(sc, h2);
+    hs[3] = group_sum(sc, h3 + c0s); hs[4] = group_sum(sc, h4); hs[5] = group_sum(sc, h5 + c0s);
 }
 
 /* SSE only (estimationError at a given position) */
