@@ -101,6 +101,24 @@ KFPOS_FN double kf_rcp(double x) {
     return 1.0 / x;
 #endif
 }
+/* fused multiply-add where the rounding has to be the same at two places of the device code; the host emulation, which
+ * is compared with the oracle to a tolerance, not with the GPU bit for bit, multiplies and adds */
+KFPOS_FN double kf_fma(double a, double b, double c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_fma(a, b, c);
+#else
+    return a * b + c;
+#endif
+}
+/* 0 that the compiler cannot see through: added to an index, it keeps a loop-invariant read of parked values inside
+ * the loop (hoisted, they would occupy registers for the whole loop) without hiding which memory the pointer is in */
+KFPOS_FN int kf_opaque_zero() {
+    int z = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(z));
+#endif
+    return z;
+}
 KFPOS_FN double kf_rsqrt(double x) {
 #if defined(__HIP_DEVICE_COMPILE__)
     double y = __builtin_amdgcn_rsq(x);
@@ -196,6 +214,9 @@ struct Params {
     int use_fixed_height, imu_fixed_cov_acc, imu_fixed_cov_w;
     double px4_height, px4_arm_p1, px4_arm_p2, px4_cov_vel, px4_cov_gyro_z;
     double imu_cov_acc, imu_cov_w, mag_offset, mag_cov;
+    const double *pair_anchor_tab = nullptr; /* 9-state kernel: [8][3] copy of the anchor table that lanes can index
+                                                individually (LDS); non-null = the tail of the gain iteration runs two
+                                                lanes per tag (iekf9_pairs) */
 };
 
 /* ------------------------------------------------------------------ 3x3 helpers */

@@ -58,6 +58,7 @@ struct KArgs {
     int T, A;
     double accel_noise, jolt, cost_threshold;
     int ignore_worst, top_n, use_init_pos;
+    int pair9;        /* 9-state kernel: two lanes per tag for the tail of the gain iteration (KFPOS_PAIR9=1; off by default: DESIGN 6a) */
     /* planar filter configuration (kfpos_planar_config) */
     int use_fixed_height, imu_fixed_cov_acc, imu_fixed_cov_w;
     double px4_height, px4_arm_p1, px4_arm_p2, px4_cov_vel, px4_cov_gyro_z;
@@ -474,7 +475,7 @@ __global__ __launch_bounds__(WAVE) void k_step_imu9(const KArgs a) {
     if (t >= (size_t)a.T) return;
     const size_t T = a.T;
     const uint32_t t32 = (uint32_t)t;
-    const Params pr = make_params(a);
+    Params pr = make_params(a);
     constexpr bool has_ranging = RANGING;
     /* the next epoch's measurements are fetched one epoch AHEAD, behind the current epoch's arithmetic -- in the
      * KFPOS_STORE_MIXED instantiation (the bench configuration); the other two (8-byte measurements: 22 more registers
@@ -503,12 +504,20 @@ __global__ __launch_bounds__(WAVE) void k_step_imu9(const KArgs a) {
     }
     uint32_t fl = a.flags[t32];
     /* the covariance and B^-1 wait in LDS while the gain iteration runs, the accelerometer whitener for the whole
-     * launch: [72][lane], behind the generic kernel's epoch scratch */
+     * launch: [78][lane], behind the generic kernel's epoch scratch */
     const CovPark9 park{lds + ((AS == 0 && has_ranging) ? 3 * (size_t)a.A * WAVE : 0) + lane, WAVE};
     Imu imu;
     imu.has = false;
     imu.ci = park.a + 66 * WAVE;
     imu.ci_stride = WAVE;
+    if constexpr (AS == 8 && RANGING) { /* the anchor table once more, where lanes can index it one by one (iekf9_pairs) */
+        if (a.pair9) {
+            double *tab = lds + 78 * WAVE;
+#pragma unroll
+            for (int k = 0; k < 24; ++k) tab[k] = a.anchors[k]; /* (every lane writes the same 24 numbers) */
+            pr.pair_anchor_tab = tab;
+        }
+    }
     double cv[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     MREAL rawc[9];
     if (fresh_imu) {
@@ -533,7 +542,7 @@ __global__ __launch_bounds__(WAVE) void k_step_imu9(const KArgs a) {
         for (int k = 0; k < 9; ++k) cv[k] = (double)rawc[k];
         if (a.latch) latch_imu_cov<MREAL>(a, T, t32, cv);
     }
-    if (imu.has) imu_whitener(cv, imu.ci, imu.ci_stride, imu.wi);
+    if (imu.has) imu_whitener(cv, imu.ci, imu.ci_stride);
 
 
     uint32_t s = 0;
@@ -929,6 +938,7 @@ struct kfpos_handle {
     bool have_anchors, stepped;
     int trace_chunk;    /* epochs per launch in kfpos_run_trace_dev (KFPOS_TRACE_CHUNK_STEPS, 1..128) */
     bool force_generic; /* KFPOS_GENERIC_KERNEL=1: always the LDS-staged kernel (A/B measurements, tests) */
+    bool pair9;         /* 9-state bank: iekf9_pairs for the tail of the gain iteration; KFPOS_PAIR9=1 enables (built, bit-identical, measured: no gain worth having -- DESIGN 6a) */
     bool coop;          /* small plain 6-state bank: one tag per 8 lanes (k_step_toa6_coop); KFPOS_NO_COOP=1 disables */
     double anchors[KFPOS_MAX_ANCHORS * 3];
     /* device state */
@@ -973,7 +983,7 @@ namespace {
 
 size_t lds_bytes(const kfpos_handle *h) { return (size_t)3 * h->cfg.max_anchors * WAVE * sizeof(double); }
 size_t park_bytes() { return (size_t)36 * WAVE * sizeof(double); } /* 36 doubles per lane: CovSpill8 (planar), Pinv6 (6-state, full) */
-size_t park9_bytes() { return (size_t)72 * WAVE * sizeof(double); } /* CovPark9: the 9-state covariance and B^-1 during the gain iteration, the accelerometer whitener */
+size_t park9_bytes() { return (size_t)78 * WAVE * sizeof(double) + 24 * sizeof(double); } /* CovPark9: the 9-state covariance (45) and B^-1 (21) during the gain iteration, the accelerometer whitener and Sigma^-1 (12), a lane-addressable copy of 8 anchors: 39.2 KB per wavefront, four wavefronts per CU */
 
 void fill_args(const kfpos_handle *h, KArgs &a) {
     std::memcpy(a.anchors, h->anchors, sizeof(a.anchors));
@@ -984,6 +994,7 @@ void fill_args(const kfpos_handle *h, KArgs &a) {
     a.cost_threshold = h->cfg.cost_threshold;
     a.ignore_worst = h->cfg.ignore_worst;
     a.top_n = h->cfg.top_n;
+    a.pair9 = h->pair9 ? 1 : 0;
     a.use_init_pos = h->cfg.use_init_pos;
     a.use_fixed_height = h->planar.use_fixed_height;
     a.imu_fixed_cov_acc = h->planar.imu_use_fixed_cov_acc;
@@ -1324,6 +1335,8 @@ int kfpos_create(const kfpos_config *cfg, kfpos_handle **out) {
     {
         const char *g = getenv("KFPOS_GENERIC_KERNEL");
         h->force_generic = g && g[0] == '1';
+        const char *np = getenv("KFPOS_PAIR9");
+        h->pair9 = np && np[0] == '1';
         const char *nc = getenv("KFPOS_NO_COOP");
         /* up to 8 192 tags (1024 groups-of-8 wavefronts = one per SIMD) 8 lanes per tag pay off: 4.4-5.0 us per epoch
          * against 7.5 us; at 16 384 the one-tag-per-lane grid wins again (7.7 vs 8.3 us, measured) */

@@ -45,7 +45,7 @@ struct kfe_bank {
     std::vector<Tag6<false>> t6f;
     std::vector<Tag9> t9;
     std::vector<Imu> imu;
-    std::vector<double> imu_ci; /* Imu::ci storage, 6 per tag (LDS on the GPU) */
+    std::vector<double> imu_ci; /* Imu::ci storage, 12 per tag (LDS on the GPU) */
     std::vector<uint32_t> flags;
     std::vector<double> ml_pos, ml_cov, ml_seed; /* model 2: standalone ML estimator */
     std::vector<Tag8> t8;                        /* model 3: planar filter */
@@ -107,11 +107,11 @@ kfe_bank *kfe_create(int model, int n_tags, int n_anchors, const double *anchors
     } else {
         b->t9.resize(n_tags);
         b->imu.resize(n_tags);
-        b->imu_ci.assign((size_t)6 * n_tags, 0.0);
+        b->imu_ci.assign((size_t)12 * n_tags, 0.0);
         for (int t = 0; t < n_tags; ++t) {
             std::memset(&b->t9[t], 0, sizeof(Tag9));
             std::memset(&b->imu[t], 0, sizeof(Imu));
-            b->imu[t].ci = &b->imu_ci[(size_t)6 * t];
+            b->imu[t].ci = &b->imu_ci[(size_t)12 * t];
             b->imu[t].ci_stride = 1;
             for (int k = 0; k < 3; ++k) b->t9[t].pos[k] = ip(t, k);
         }
@@ -224,7 +224,7 @@ void kfe_latch_imu(kfe_bank *b, const double *accel, const double *cov) {
         Imu &im = b->imu[t];
         im.has = true;
         for (int k = 0; k < 3; ++k) im.acc[k] = accel[3 * t + k];
-        imu_whitener(cov + 9 * (size_t)t, im.ci, im.ci_stride, im.wi);
+        imu_whitener(cov + 9 * (size_t)t, im.ci, im.ci_stride);
         b->flags[t] |= FL_HAS_IMU;
     }
 }

@@ -76,7 +76,7 @@ _emu = None
 def emu_lib():
     global _emu
     if _emu is None:
-        L = C.CDLL(os.path.join(ROOT, "tests", "emu", "libkfpos_emu.so"))
+        L = C.CDLL(os.environ.get("KFPOS_EMU_LIB") or os.path.join(ROOT, "tests", "emu", "libkfpos_emu.so"))
         dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
         ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
         L.kfe_create.restype = C.c_void_p
