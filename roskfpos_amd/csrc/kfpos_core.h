@@ -119,6 +119,14 @@ KFPOS_FN int kf_opaque_zero() {
 #endif
     return z;
 }
+/* index of the lowest set bit of a non-zero mask */
+KFPOS_FN int kf_ctz64(uint64_t m) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __ffsll((unsigned long long)m) - 1;
+#else
+    return __builtin_ctzll(m);
+#endif
+}
 KFPOS_FN double kf_rsqrt(double x) {
 #if defined(__HIP_DEVICE_COMPILE__)
     double y = __builtin_amdgcn_rsq(x);
@@ -336,6 +344,7 @@ struct Scratch {
     KFPOS_HD void setW(int a, double v) { w[a * stride] = v; }
     KFPOS_HD double Rdyn(int a) const { return r[a * stride]; } /* a not a compile-time constant */
     KFPOS_HD double Edyn(int a) const { return e[a * stride]; }
+    KFPOS_HD void setWdyn(int a, double v) { w[a * stride] = v; }
 };
 /* Scratch with the anchor count fixed at compile time but the epoch still outside the register file: the anchor
  * loops unroll (coordinates become batched constant-offset scalar loads, the LDS reads of a sweep are issued
@@ -366,6 +375,7 @@ struct StaticScratchF {
     KFPOS_HD void setW(int a, double v) { w[a * stride] = v; }
     KFPOS_HD double Rdyn(int a) const { return r[a * stride]; }
     KFPOS_HD double Edyn(int a) const { return (double)e[a * stride]; }
+    KFPOS_HD void setWdyn(int a, double v) { w[a * stride] = v; }
 };
 /* Same view with the anchor count fixed at compile time: the epoch stays in registers, every anchor
  * loop unrolls, anchor coordinates become constant-offset scalar loads that the compiler batches. */
@@ -391,6 +401,10 @@ struct RegScratch {
         for (int k = 0; k < N; ++k) v = (k == a) ? e[k] : v;
         return v;
     }
+    KFPOS_HD void setWdyn(int a, double v) {
+        KFPOS_UNROLL
+        for (int k = 0; k < N; ++k) w[k] = (k == a) ? v : w[k];
+    }
 };
 /* One tag per GROUP OF 8 LANES, one anchor per lane. For small batches (a few thousand tags) the machine is mostly
  * empty and what bounds a step is the instruction chain of a single lane; here the anchor sweeps of a tag -- most of
@@ -408,6 +422,7 @@ struct CoopScratch {
     KFPOS_HD void setW(int, double v) { w = v; }
     KFPOS_HD double Rdyn(int) const { return 0.0; } /* leave-one-out is not offered in this mode */
     KFPOS_HD double Edyn(int) const { return 1.0; }
+    KFPOS_HD void setWdyn(int, double) {}
 };
 
 /* coordinates of anchor column a */

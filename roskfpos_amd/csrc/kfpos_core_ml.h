@@ -92,6 +92,13 @@ KFPOS_FN void ml_terms_of(const double p[3], const Params &pr, int v, double r, 
     t.hs[3] = ty * dy + c0; t.hs[4] = ty * dz; t.hs[5] = tz * dz + c0;
 }
 
+/* the same for an anchor index that differs from lane to lane (the ranges a top-N composition dropped): the anchor
+ * table is read with a vector load. v must be a valid index on every lane; w = 0 yields exact zeros. */
+template <class SC>
+KFPOS_FN void ml_terms_of_lane(const double p[3], const Params &pr, int v, double r, double w, MlFirst &t) {
+    ml_terms_of<SC>(p, pr, v, r, w, t);
+}
+
 /* Gauss-Newton loop of MLLocation.cpp:164-225. p: seed in, estimate out. Requires sc.w = 1/e.
  * Returns the iteration count; sse_out = estimationError at the result. With n_used < 4 the
  * seed is returned untouched (MLLocation.cpp:158-161). The step p - Hs^-1 g equals the
@@ -201,14 +208,53 @@ KFPOS_FN void set_weights_iekf(SC &sc, const Params &pr, double e_ml, uint64_t d
 }
 
 /* Top-N composition (BASELINE config 5; MLLocation.cpp:284-300, 325-339): rank the residual^2
- * at the ML position of all ranges, drop the min(n-4, N) largest. Returns the drop mask. */
-template <class SC>
-KFPOS_FN uint64_t topn_mask(const double seed[3], SC &sc, const Params &pr, int n_valid) {
+ * at the ML position of all ranges, drop the min(n-4, N) largest. Returns the drop mask.
+ * SHARE (the top-N-only kernels): the caller's next solve starts at the same seed over the kept ranges, so
+ *  - first_all receives the gradient / Hessian sums of this solve's first sweep (the caller subtracts the dropped
+ *    anchors' terms instead of sweeping again), and
+ *  - with at most two ranges to drop the two largest residuals are tracked in registers while they are computed, the
+ *    working weights (1/e of every used range) stay where they are and only the dropped ones are zeroed: on return
+ *    weights_kept says that the weights of the kept set are already in place (set_weights_ml(sc, pr, drop) done). */
+template <bool SHARE, class SC>
+KFPOS_FN uint64_t topn_mask(const double seed[3], SC &sc, const Params &pr, int n_valid, MlFirst &first_all,
+                            bool &first_valid, bool &weights_kept) {
+    weights_kept = false;
+    first_valid = false;
     int ndrop = n_valid - 4 < pr.top_n ? n_valid - 4 : pr.top_n;
     if (ndrop <= 0) return 0;
+    first_valid = SHARE; /* n_valid >= 5 here: the solve below does sweep */
     double p[3] = {seed[0], seed[1], seed[2]}, sse;
     set_weights_ml(sc, pr, 0ull);
-    ml_estimate(p, sc, pr, 0, n_valid, sse);
+    MlFirst unused = {};
+    ml_estimate(p, sc, pr, 0, n_valid, sse, false, unused, SHARE, first_all);
+    uint64_t drop = 0;
+    if (SHARE && ndrop <= 2) {
+        double v1 = -1.0, v2 = -1.0; /* largest, second largest residual^2; an absent range (-1) never gets in */
+        int i1 = -1, i2 = -1;
+        for_anchors<SC>(pr, [&](int a) {
+            const double dx = pr.anchors[3 * a] - p[0], dy = pr.anchors[3 * a + 1] - p[1], dz = pr.anchors[3 * a + 2] - p[2];
+            double d, invd;
+            kf_sqrt_rsqrt(dx * dx + dy * dy + dz * dz, d, invd);
+            const double rd = d - sc.R(a);
+            const double r2 = used(sc, a, 0) ? rd * rd : -1.0;
+            /* the order of the selection passes below: the first of equal values wins, the next one comes second */
+            const bool first = r2 > v1, second = !first && r2 > v2;
+            v2 = first ? v1 : (second ? r2 : v2);
+            i2 = first ? i1 : (second ? a : i2);
+            v1 = first ? r2 : v1;
+            i1 = first ? a : i1;
+        });
+        if (i1 >= 0) {
+            drop |= 1ull << i1;
+            sc.setWdyn(i1, 0.0);
+        }
+        if (ndrop == 2 && i2 >= 0) {
+            drop |= 1ull << i2;
+            sc.setWdyn(i2, 0.0);
+        }
+        weights_kept = true;
+        return drop;
+    }
     /* residual^2 of every range at the ML position, once, into the working-weight slots (free between the two solves:
      * the caller sets the weights of the kept set afterwards); then ndrop selection passes over those 16 numbers
      * instead of ndrop passes that each recompute all the distances */
@@ -219,7 +265,6 @@ KFPOS_FN uint64_t topn_mask(const double seed[3], SC &sc, const Params &pr, int 
         const double rd = d - sc.R(a);
         sc.setW(a, used(sc, a, 0) ? rd * rd : -1.0); /* an absent range never wins: every real residual^2 is >= 0 */
     });
-    uint64_t drop = 0;
     for (int k = 0; k < ndrop; ++k) {
         double worst = -1.0;
         int wi = -1;
@@ -233,6 +278,12 @@ KFPOS_FN uint64_t topn_mask(const double seed[3], SC &sc, const Params &pr, int 
         drop |= 1ull << wi;
     }
     return drop;
+}
+template <class SC>
+KFPOS_FN uint64_t topn_mask(const double seed[3], SC &sc, const Params &pr, int n_valid) {
+    MlFirst unused = {};
+    bool valid, kept;
+    return topn_mask<false>(seed, sc, pr, n_valid, unused, valid, kept);
 }
 
 /* ================================================================== standalone ML estimator (ALGORITHM_ML) */

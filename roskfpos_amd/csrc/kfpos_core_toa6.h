@@ -183,10 +183,11 @@ struct Iekf6Out {
  * loads are still in flight. Leaves sc.w = 1/R. */
 template <class SC>
 KFPOS_FN void iekf6_weights(const double xhat_p[3], SC &sc, const Params &pr, uint64_t drop, int n_used,
-                            Iekf6Out &o, bool use_first, const MlFirst &first, bool keep_first, MlFirst &first_out) {
+                            Iekf6Out &o, bool use_first, const MlFirst &first, bool keep_first, MlFirst &first_out,
+                            bool weights_ready = false) {
     o.flags = (n_used < 4) ? ST_FEW_RANGES : 0u;
     double pml[3] = {xhat_p[0], xhat_p[1], xhat_p[2]}, e_ml;
-    set_weights_ml(sc, pr, drop);
+    if (!weights_ready) set_weights_ml(sc, pr, drop); /* (the top-N ranking may have left them in place) */
     o.ml_iters = ml_estimate(pml, sc, pr, drop, n_used, e_ml, use_first, first, keep_first, first_out);
     if (ml_covariance_throws(sc, pr, drop, n_used, e_ml)) o.flags |= ST_UPDATE_SKIPPED;
     if (isnan(pml[0]) || isnan(pml[1]) || isnan(pml[2])) {
@@ -357,8 +358,31 @@ KFPOS_FN uint32_t step_toa6(Tag6<SYMM> &tg, SC &sc, const Params &pr_in, double 
         return pack_status(ST_ML_INIT, 0, it, -1);
     }
     uint64_t drop = 0;
+    /* top-N only (HEUR == 1): the solve that ranks the residuals and the filter's own solve start at the same seed, so
+     * the second one gets its first sweep from the first one's (minus the dropped ranges' terms), and the working
+     * weights of the kept set straight from the ranking (topn_mask<true>) */
+    constexpr bool SHARE_TOPN = HEUR == 1 && SYMM && !SC::COOP;
+    MlFirst first_top = {};
+    bool top_shared = false, top_weights = false;
     if (pr.top_n > 0 && !(isnan(tg.pos[0]) || isnan(tg.pos[1]) || isnan(tg.pos[2]))) {
-        drop = topn_mask(tg.pos, sc, pr, n_valid);
+        bool first_valid = false;
+        drop = topn_mask<SHARE_TOPN>(tg.pos, sc, pr, n_valid, first_top, first_valid, top_weights);
+        if (SHARE_TOPN && first_valid) { /* (nothing to drop: no ranking solve has run) */
+            uint64_t rest = drop;
+            KFPOS_UNROLL
+            for (int k = 0; k < 2; ++k) { /* up to two dropped ranges are taken out of the sums; a lane with more sweeps as before */
+                const bool any = rest != 0;
+                const int v = any ? kf_ctz64(rest) : 0;
+                MlFirst t;
+                ml_terms_of_lane<SC>(tg.pos, pr, v, sc.Rdyn(v), any ? kf_rcp(sc.Edyn(v)) : 0.0, t);
+                KFPOS_UNROLL
+                for (int j = 0; j < 3; ++j) first_top.g[j] -= t.g[j];
+                KFPOS_UNROLL
+                for (int j = 0; j < 6; ++j) first_top.hs[j] -= t.hs[j];
+                rest &= rest - 1;
+            }
+            top_shared = rest == 0; /* more than two dropped: this lane sweeps as before */
+        }
         n_valid = count_used(sc, pr, drop);
     }
     const double xhat_p[3] = {tg.pos[0], tg.pos[1], tg.pos[2]}; /* F x: velocity restarts at 0 */
@@ -418,7 +442,14 @@ KFPOS_FN uint32_t step_toa6(Tag6<SYMM> &tg, SC &sc, const Params &pr_in, double 
                 use_first = true;
             }
         }
-        iekf6_weights(xhat_p, sc, pr, mask, n_use, o, use_first, f, keep_first, first_all);
+        if constexpr (SHARE_TOPN) {
+            if (last && top_shared) {
+                f = first_top;
+                use_first = true;
+            }
+        }
+        iekf6_weights(xhat_p, sc, pr, mask, n_use, o, use_first, f, keep_first, first_all,
+                      SHARE_TOPN && last && top_weights);
         if (!predicted) { /* after the first ML solve: the covariance loads have landed by now */
             predict6(tg.P, dt, pr.accel_noise);
             predicted = true;
