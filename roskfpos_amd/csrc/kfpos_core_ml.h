@@ -200,10 +200,17 @@ template <class SC>
 KFPOS_FN void set_weights_ml(SC &sc, const Params &pr, uint64_t drop) {
     for_anchors<SC>(pr, [&](int a) { sc.setW(a, used(sc, a, drop) ? kf_rcp(sc.E(a)) : 0.0); });
 }
+/* REQUIRES the weights of set_weights_ml(sc, pr, drop) in place: 1 / max(e_ML, e_a) is either that weight (1 / e_a,
+ * the same kf_rcp of the same number) or 1 / e_ML, one reciprocal for all anchors instead of one per anchor */
 template <class SC>
 KFPOS_FN void set_weights_iekf(SC &sc, const Params &pr, double e_ml, uint64_t drop) {
-    for_anchors<SC>(pr, [&](int a) { /* KalmanFilterTOA.cpp:281 */
-        sc.setW(a, used(sc, a, drop) ? kf_rcp(stdmax(e_ml, sc.E(a))) : 0.0);
+    if constexpr (SC::COOP) { /* one anchor per lane: one reciprocal either way, the direct form is shorter */
+        sc.setW(0, used(sc, 0, drop) ? kf_rcp(stdmax(e_ml, sc.E(0))) : 0.0);
+        return;
+    }
+    const double r_ml = kf_rcp(e_ml);
+    for_anchors<SC>(pr, [&](int a) { /* KalmanFilterTOA.cpp:281; stdmax(e_ml, e) = e_ml < e ? e : e_ml */
+        sc.setW(a, used(sc, a, drop) ? ((e_ml < sc.E(a)) ? sc.W(a) : r_ml) : 0.0);
     });
 }
 

@@ -11,7 +11,7 @@ for E in 25 5; do
   rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write_$E --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-per-epoch --epochs-per-launch $E --steps 100 --warmup 25 > $OUT/write_$E.log 2>&1
 done
 cd $R
-python3 tools/traffic_summary.py --match k_step_imu9 --key "k_step_imu9<double,float,8>" --tags 65536 --run 25 $OUT/fetch_25 $OUT/write_25 --run 5 $OUT/fetch_5 $OUT/write_5 --note "bench.py --no-cpu-baseline --no-per-epoch --steps 100 --warmup 25 at 25 and 5 epochs per launch ($1)" --merge $OUT/traffic_latest.json > /dev/null
+python3 tools/traffic_summary.py --match k_step_imu9 --key "k_step_imu9<double,float,8,true>" --tags 65536 --run 25 $OUT/fetch_25 $OUT/write_25 --run 5 $OUT/fetch_5 $OUT/write_5 --note "bench.py --no-cpu-baseline --no-per-epoch --steps 100 --warmup 25 at 25 and 5 epochs per launch ($1)" --merge $OUT/traffic_latest.json > /dev/null
 python3 tools/traffic_summary.py --match k_step_toa6 --key "k_step_toa6<true,double,double,8,0>" --tags 65536 --run 25 $OUT/fetch_25 $OUT/write_25 --run 5 $OUT/fetch_5 $OUT/write_5 --note "the secondary 6-state line of the same runs ($1)" --merge $OUT/traffic_latest.json > /dev/null
 cat $OUT/traffic_latest.json | head -40
 for d in stats_driver stats_default; do f=$(find $OUT/$d -name "*kernel_stats.csv" | head -1); cp $f $OUT/${d}_kernel_stats.csv; head -6 $f | cut -c1-160; done

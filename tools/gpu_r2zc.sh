@@ -1,0 +1,10 @@
+set -e
+true
+mkdir -p gpurun_out/libs_ab; bash tools/gpu_libs_ab.sh ml,c2,toa6_65k,c4shard,c3,c5,iw8,planar,planar_sens head:tools/exp/_build/libkfpos_head.so new:roskfpos_amd/csrc/libkfpos_hip.so > gpurun_out/libs_ab/log.txt 2>&1
+python - <<'PY'
+import json,collections
+d=collections.defaultdict(list)
+for l in open("gpurun_out/libs_ab/ab.jsonl"):
+    r=json.loads(l); d[(r["config"],r["variant"])].append(r["us"])
+for k,v in sorted(d.items()): print(k, round(sum(v)/len(v),2), v)
+PY
