@@ -636,7 +636,9 @@ KFPOS_FN int nth_set_bit(uint64_t m, int n) {
  * weights come over by ds_bpermute, its B^-1 is read where its owner parked it, the anchors from a copy of the anchor
  * table in LDS (anchor_tab: [8][3], selected by lane parity). Each lane of a pair sweeps four of the eight anchors, one exchange (quad_perm [1,0,3,2]) completes the ten sums -- (0-3) + (4-7), exactly what the
  * owner would have formed -- and both lanes run the pass on identical numbers. Results go back to the owners, which
- * cannot tell that it happened: same bits. */
+ * cannot tell that it happened: same bits. (The sweep is written with explicit fma for that; the pass is the same
+ * inlined function at both places, and that the compiler contracts it the same way twice is what
+ * tests/test_pairs9_gpu.py checks on every build -- it is not a guarantee of the language.) */
 template <bool DIAG, bool ACC0>
 KFPOS_FN void iekf9_pairs(uint64_t m, const double xhat[9], const double *binv, int binv_stride,
                           const RegScratch<8> &sc, const double *anchor_tab, const Imu &imu, int max_steps, double tol,

@@ -57,6 +57,11 @@ CASES = [
     Case("toa6_A8_mlinit", MODEL_TOA, 8, fixed=False),
     Case("toa6_A8_ignoreworst", MODEL_TOA, 8, ignore_worst=True, outlier=True),
     Case("toa6_A16_top2", MODEL_TOA, 16, top_n=2, outlier=True),
+    # top-N only with other counts than BASELINE config 5's: one range dropped (ranking in registers, one anchor's terms
+    # taken out of the shared first sweep), three (selection passes; the lane sweeps the kept set itself), and with
+    # 8 anchors every third tag of the s % 11 == 5 epochs has 2 ranges, others 7: ndrop runs through 0..N
+    Case("toa6_A8_top1", MODEL_TOA, 8, top_n=1, outlier=True, T=32, S=50),
+    Case("toa6_A16_top3", MODEL_TOA, 16, top_n=3, outlier=True, T=32, S=50),
     Case("imu9_A8_fixed", MODEL_TOA_IMU, 8),
     Case("imu9_A8_mlinit", MODEL_TOA_IMU, 8, fixed=False),
     Case("imu9_A8_latched", MODEL_TOA_IMU, 8, imu_every=3, cov_full=True),
