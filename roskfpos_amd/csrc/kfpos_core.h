@@ -56,15 +56,6 @@
 #define KFPOS_WAVE_ALL(pred) (pred)
 #endif
 
-/* The instruction scheduler may not move anything across this point (device code; nothing on the host). Used where
- * a large object has just been parked outside the register file: without the fence the scheduler overlaps what comes
- * next with the parking stores and both live sets coexist. */
-#if defined(__HIP_DEVICE_COMPILE__)
-#define KFPOS_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-#else
-#define KFPOS_SCHED_FENCE() ((void)0)
-#endif
-
 namespace kfpos {
 
 /* per-tag status word (include/kfpos.h repeats these as KFPOS_ST_*) */

@@ -571,7 +571,7 @@ KFPOS_FN bool iekf9_pass(const double xhat[9], const Iekf9Parked &pk, const Imu 
         }
     }
     if (rel_change_below(it.cost, c, tol)) return false; /* KalmanFilterTOAIMU.cpp:316 */
-#ifdef KFPOS_EMU_ITER_TRACE
+#ifdef KFPOS_EMU_ITER_TRACE /* tools/exp/iter_cycle.py: a host build that records every iterate */
     kfpos_emu_iter_trace(o.gain_iters, ve, c);
 #endif
     it.cost = c;
@@ -881,9 +881,6 @@ KFPOS_FN uint32_t step_imu9(Tag9 &tg, SC &sc, const Params &pr, double dt, const
     }
     /* per lane, not per wavefront: a tag's arithmetic must not depend on its wave-mates (a wavefront whose lanes
      * disagree runs both forms one after the other, each under its lanes' mask) */
-#ifdef KFPOS_EMU_STATS
-    kfpos_emu_stats[invertible ? 0 : 1]++;
-#endif
     if (invertible) {
         iekf9_info<false, RANGING, true>(xhat, binv, park.stride, sc, pr, imu, 20, 1e-4, o);
         KFPOS_UNROLL
