@@ -1,7 +1,7 @@
 set -e
-timeout -k 10 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+timeout -k 10 900 python -m pytest tests/test_pairs9_gpu.py tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -3
 mkdir -p gpurun_out/libs_ab
-bash tools/gpu_libs_ab.sh c4shard,toa6_65k,c5,c3 cur:tools/exp/_build/libkfpos_cur.so new:roskfpos_amd/csrc/libkfpos_hip.so > gpurun_out/libs_ab/log.txt 2>&1
+bash tools/gpu_libs_ab.sh c3 cur:tools/exp/_build/libkfpos_cur.so new:roskfpos_amd/csrc/libkfpos_hip.so pairs:roskfpos_amd/csrc/libkfpos_hip.so:KFPOS_PAIR9=1 > gpurun_out/libs_ab/log.txt 2>&1
 python - <<'PY'
 import json,collections
 d=collections.defaultdict(list)
@@ -9,4 +9,3 @@ for l in open("gpurun_out/libs_ab/ab.jsonl"):
     r=json.loads(l); d[(r["config"],r["variant"])].append(r["us"])
 for k,v in sorted(d.items()): print(k, round(sum(v)/len(v),2), v)
 PY
-timeout -k 10 600 python bench.py --config c4 --steps 40 --warmup 10 --no-cpu-baseline 2>/dev/null | grep '^{"metric"' | cut -c1-250
