@@ -330,10 +330,18 @@ KFPOS_FN void cov_update6(Cov<6, SYMM> &P, const double m[6], bool pivot) {
  * guarantees ignore_worst = 0), 0: none (ignore_worst = 0 and top_n = 0). Knowing it at compile time lets the
  * compiler drop the leave-one-out loop and the kept results: fewer instructions and registers for the plain filter
  * of BASELINE configs 2 and 4 and for the top-N composition of config 5. */
-template <bool SYMM, int HEUR = 2, class SC>
+/* PARKN (symmetric layout only): the first PARKN covariance entries wait at park[k * park_stride] (LDS) while the
+ * ML solve runs -- it does not touch P -- so that the solve has their registers: what lets the plain filter fit 256
+ * registers, two wavefronts per SIMD (k_step_toa6_w2). */
+template <bool SYMM, int HEUR = 2, int PARKN = 0, class SC>
 KFPOS_FN uint32_t step_toa6(Tag6<SYMM> &tg, SC &sc, const Params &pr_in, double dt, double *park = nullptr,
                             int park_stride = 0) {
+    static_assert(PARKN == 0 || SYMM, "the parking slots of the non-symmetric layout hold its pseudo-inverse");
     Params pr = pr_in;
+    if constexpr (PARKN > 0) {
+        KFPOS_UNROLL
+        for (int k = 0; k < PARKN; ++k) park[k * park_stride] = tg.P.a[k];
+    }
     if (HEUR < 2) pr.ignore_worst = 0;
     if (HEUR < 1) pr.top_n = 0;
     int n_valid = count_used(sc, pr, 0);
@@ -451,6 +459,10 @@ KFPOS_FN uint32_t step_toa6(Tag6<SYMM> &tg, SC &sc, const Params &pr_in, double 
         iekf6_weights(xhat_p, sc, pr, mask, n_use, o, use_first, f, keep_first, first_all,
                       SHARE_TOPN && last && top_weights);
         if (!predicted) { /* after the first ML solve: the covariance loads have landed by now */
+            if constexpr (PARKN > 0) {
+                KFPOS_UNROLL
+                for (int k = 0; k < PARKN; ++k) tg.P.a[k] = park[k * park_stride];
+            }
             predict6(tg.P, dt, pr.accel_noise);
             predicted = true;
             if constexpr (!SYMM) {

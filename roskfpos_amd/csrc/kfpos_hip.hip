@@ -311,6 +311,72 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(1, 2))) vo
     if (a.status) a.status[t] = s;
 }
 
+/* The plain 8-anchor 6-state step (symmetric layout, no outlier heuristic) in at most 256 registers, for banks with
+ * more wavefronts than the chip has SIMDs (> 65 536 tags). Left to itself the compiler gives the register-resident
+ * kernel above 305 registers: one wavefront per SIMD, which is all a bank of up to 65 536 tags can use -- but a bank
+ * of 131 072 tags (BASELINE configs[3] on 8 GPUs) then runs as two rounds of one wavefront per SIMD instead of one
+ * round of two that fill each other's idle cycles. Here the epoch sits in LDS ([anchor][lane], compile-time loops 8
+ * wide as above) and most of the covariance joins it while the ML solve runs (step_toa6<..., PARKN>): 19.5 KB per
+ * wavefront, eight wavefronts per CU. Same arithmetic, same bits (tests/test_two_waves_gpu.py). */
+template <typename MREAL>
+constexpr int toa6_w2_park() { return sizeof(MREAL) == 4 ? 19 : 15; } /* what 160 KB / 8 leave next to the epoch */
+template <typename REAL, typename MREAL>
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_step_toa6_w2(const KArgs a) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const size_t t = (size_t)blockIdx.x * WAVE + lane;
+    if (t >= (size_t)a.T) return;
+    const size_t T = a.T;
+    const uint32_t t32 = (uint32_t)t;
+    const Params pr = make_params(a);
+    if (a.n_steps == 1 && a.dt && a.dt[t] < 0.0) { /* no epoch for this tag in this call */
+        skipped_lane(a, t, true);
+        return;
+    }
+    Tag6<true> tg;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) tg.pos[k] = (a.pos + k * T)[t32];
+#pragma unroll
+    for (int k = 0; k < Cov<6, true>::SZ; ++k) tg.P.a[k] = ldrow<REAL>(a.P, k, T, t32);
+    double *park = lds + static_epoch_doubles<MREAL, 8>() + lane;
+    constexpr int PARKN = toa6_w2_park<MREAL>();
+    uint32_t s = 0;
+    for (int e = 0; e < a.n_steps; ++e) {
+        const double dt = epoch_dt(a, opaque_lane(t), e);
+        if constexpr (sizeof(MREAL) == 4) {
+            StaticScratchF<8> sc = stage_epoch_lds_nf<8>(a, lds, lane, opaque_lane(t), opaque_uniform(e));
+            s = step_toa6<true, 0, PARKN>(tg, sc, pr, dt, park, WAVE);
+        } else {
+            StaticScratch<8> sc = stage_epoch_lds_n<MREAL, 8>(a, lds, lane, opaque_lane(t), opaque_uniform(e));
+            s = step_toa6<true, 0, PARKN>(tg, sc, pr, dt, park, WAVE);
+        }
+        if (a.traj) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) (a.traj + ((size_t)opaque_uniform(e) * 3 + k) * T)[t32] = tg.pos[k];
+        }
+        if constexpr (sizeof(REAL) == 4) { /* what n single-epoch launches would have kept in HBM */
+            if (e + 1 < a.n_steps) {
+#pragma unroll
+                for (int k = 0; k < Cov<6, true>::SZ; ++k) tg.P.a[k] = (double)(float)tg.P.a[k];
+            }
+        }
+    }
+    bool fin = true;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        (a.pos + k * T)[t32] = tg.pos[k];
+        fin &= isfinite(tg.pos[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < Cov<6, true>::SZ; ++k) {
+        strow<REAL>(a.P, k, T, t32, tg.P.a[k]);
+        fin &= isfinite(tg.P.a[k]);
+    }
+    if (!fin) s |= ST_NONFINITE; /* (a symmetric-layout bank has a fixed start: no tag waits for an initialisation) */
+    a.flags[t] |= FL_STARTED;
+    if (a.status) a.status[t] = s;
+}
+
 /* ------------------------------------------------------------------ 6-state step kernel, small batches */
 /* One tag per group of 8 lanes, one anchor per lane (kfpos_core.h: CoopScratch): for banks of a few thousand tags
  * the chip is mostly empty and a step costs the instruction chain of one lane, so the anchor sweeps are spread
@@ -938,6 +1004,7 @@ struct kfpos_handle {
     bool have_anchors, stepped;
     int trace_chunk;    /* epochs per launch in kfpos_run_trace_dev (KFPOS_TRACE_CHUNK_STEPS, 1..128) */
     bool force_generic; /* KFPOS_GENERIC_KERNEL=1: always the LDS-staged kernel (A/B measurements, tests) */
+    bool two_waves;     /* n_tags / 64 exceeds the device's SIMD count (KFPOS_ONE_WAVE_BUILD=1: never) */
     bool pair9;         /* 9-state bank: iekf9_pairs for the tail of the gain iteration; KFPOS_PAIR9=1 enables (built, bit-identical, measured: no gain worth having -- DESIGN 6a) */
     bool coop;          /* small plain 6-state bank: one tag per 8 lanes (k_step_toa6_coop); KFPOS_NO_COOP=1 disables */
     double anchors[KFPOS_MAX_ANCHORS * 3];
@@ -1043,6 +1110,11 @@ typedef void (*step_kernel_t)(const KArgs);
  * (236-960 bytes/lane of scratch) match the oracle and repeat bit for bit on full, partially filled and
  * skipped-lane wavefronts (tools/exp/, profiles/r02b_*) -- and a MemorySanitizer build of the kernel body with every
  * undefined input poisoned is clean (tests/emu/msan_audit.sh). DESIGN.md section 2. */
+/* the plain 8-anchor 6-state bank with more wavefronts than SIMDs: the two-wavefronts-per-SIMD build (k_step_toa6_w2) */
+bool toa6_two_waves(const kfpos_handle *h) {
+    return h->two_waves && h->cfg.model == KFPOS_MODEL_TOA && !h->full && !h->force_generic && !h->coop &&
+           h->cfg.max_anchors == 8 && h->cfg.ignore_worst == 0 && h->cfg.top_n == 0;
+}
 int static_anchors(const kfpos_handle *h) {
     if (h->cfg.max_anchors == 8) return 8;
     /* 16 anchors (BASELINE config 5): compile-time loops over an LDS-resident epoch (StaticScratch), 6-state only */
@@ -1051,10 +1123,11 @@ int static_anchors(const kfpos_handle *h) {
 }
 
 template <bool SYMM, typename REAL, typename MREAL>
-step_kernel_t toa6_kernel(int as, int heur) {
+step_kernel_t toa6_kernel(int as, int heur, bool two_waves = false) {
     /* heur: 0 = the bank has no outlier heuristic (BASELINE configs 2 and 4), 1 = top-N only (config 5), 2 = leave-one-out
      * (with or without top-N). 0 and 1 get instantiations with no leave-one-out loop compiled in: 13 % faster at 8 anchors */
     if constexpr (SYMM) {
+        if (as == 8 && heur == 0 && two_waves) return k_step_toa6_w2<REAL, MREAL>;
         if (as == 8) return heur ? k_step_toa6<true, REAL, MREAL, 8> : k_step_toa6<true, REAL, MREAL, 8, 0>;
     } else {
         /* non-symmetric layout (ML initialisation): its SVD path needs the registers a resident epoch would take
@@ -1110,9 +1183,10 @@ step_kernel_t step_kernel(const kfpos_handle *h, bool sensor_call = false, bool 
             return st == KFPOS_STORE_F32 ? toa6_kernel<false, float, float>(as, heur)
                  : st == KFPOS_STORE_MIXED ? toa6_kernel<false, double, float>(as, heur)
                                            : toa6_kernel<false, double, double>(as, heur);
-        return st == KFPOS_STORE_F32 ? toa6_kernel<true, float, float>(as, heur)
-             : st == KFPOS_STORE_MIXED ? toa6_kernel<true, double, float>(as, heur)
-                                       : toa6_kernel<true, double, double>(as, heur);
+        const bool w2 = toa6_two_waves(h); /* more wavefronts than SIMDs: the 256-register build of the plain kernel */
+        return st == KFPOS_STORE_F32 ? toa6_kernel<true, float, float>(as, heur, w2)
+             : st == KFPOS_STORE_MIXED ? toa6_kernel<true, double, float>(as, heur, w2)
+                                       : toa6_kernel<true, double, double>(as, heur, w2);
     }
     return st == KFPOS_STORE_F32 ? imu9_kernel<float, float>(as, !imu_only)
          : st == KFPOS_STORE_MIXED ? imu9_kernel<double, float>(as, !imu_only) : imu9_kernel<double, double>(as, !imu_only);
@@ -1129,7 +1203,7 @@ int launch_step(kfpos_handle *h, const KArgs &a, hipStream_t s) {
     const int blocks = (h->cfg.n_tags + WAVE - 1) / WAVE;
     /* does the selected kernel stage the epoch in LDS? */
     const bool generic = h->force_generic || static_anchors(h) <= 0 || (h->cfg.model == KFPOS_MODEL_TOA && h->full) ||
-                         (h->cfg.model == KFPOS_MODEL_PLANAR && h->planar_sensors);
+                         (h->cfg.model == KFPOS_MODEL_PLANAR && h->planar_sensors) || toa6_two_waves(h);
     const bool planar_sensor = h->cfg.model == KFPOS_MODEL_PLANAR && a.mode != 0;
     size_t lds = (a.mode == MODE_IMU_ONLY || planar_sensor || !generic) ? 0 : lds_bytes(h);
     /* the 6-state compile-time-count kernels keep 4-byte errorEstimations as they are: 20 bytes per anchor and lane */
@@ -1137,6 +1211,7 @@ int launch_step(kfpos_handle *h, const KArgs &a, hipStream_t s) {
         lds = lds * 5 / 6;
     if (h->cfg.model == KFPOS_MODEL_PLANAR && (h->planar_sensors || planar_sensor)) lds += park_bytes();
     if (h->cfg.model == KFPOS_MODEL_TOA && h->full) lds += park_bytes(); /* Pinv6 of the non-symmetric layout */
+    if (toa6_two_waves(h)) lds += (size_t)(h->msz == 4 ? 19 : 15) * WAVE * sizeof(double); /* covariance entries parked during the ML solve */
     if (h->cfg.model == KFPOS_MODEL_TOA_IMU) lds += park9_bytes();
     hipLaunchKernelGGL(step_kernel(h, planar_sensor, a.mode == MODE_IMU_ONLY && h->cfg.model == KFPOS_MODEL_TOA_IMU), dim3(blocks), dim3(WAVE), lds, s, a);
     HIPCHK(hipGetLastError());
@@ -1335,6 +1410,13 @@ int kfpos_create(const kfpos_config *cfg, kfpos_handle **out) {
     {
         const char *g = getenv("KFPOS_GENERIC_KERNEL");
         h->force_generic = g && g[0] == '1';
+        {
+            hipDeviceProp_t prop;
+            const char *ow = getenv("KFPOS_ONE_WAVE_BUILD");
+            h->two_waves = false;
+            if (!(ow && ow[0] == '1') && hipGetDeviceProperties(&prop, cfg->device) == hipSuccess)
+                h->two_waves = ((size_t)cfg->n_tags + WAVE - 1) / WAVE > (size_t)prop.multiProcessorCount * 4;
+        }
         const char *np = getenv("KFPOS_PAIR9");
         h->pair9 = np && np[0] == '1';
         const char *nc = getenv("KFPOS_NO_COOP");
