@@ -510,9 +510,10 @@ KFPOS_FN void iekf9_sweep(const double p[3], const SC &sc, const Params &pr, Swe
 /* What a pass reads from the park: B^-1 and Sigma^-1. Fetched at the top of every trip, BEFORE the sweep, so that the
  * LDS round trip hides behind the sweep's arithmetic instead of stalling the solve (one wavefront per SIMD: nothing else
  * would cover it); 54 registers that are free while the sweep runs. */
-/* A wavefront issues in order: fourteen LDS reads in a row at the top of a trip hold back the sweep's arithmetic until
- * the LDS queue (shared by the CU's four wavefronts) has taken them all -- measured: 250 cycles per trip. Spread over
- * the sweep, one read per dozen arithmetic instructions, they cost nothing. */
+/* The pairs' loop reads its parked values in every trip; this asks the scheduler to spread those reads over the sweep,
+ * one per ten arithmetic instructions, instead of queueing them in a row at the top of the trip (a wavefront issues in
+ * order, and the CU's four wavefronts share one LDS queue). For the one-tag-per-lane loop neither placement beat letting
+ * the compiler keep the values in registers. */
 KFPOS_FN void iekf9_spread_reads() {
 #if defined(__HIP_DEVICE_COMPILE__)
     KFPOS_UNROLL
