@@ -1,6 +1,7 @@
 set -e
+timeout -k 10 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
 mkdir -p gpurun_out/libs_ab
-bash tools/gpu_libs_ab.sh c3,c5,toa6_65k,c4shard ship:roskfpos_amd/csrc/libkfpos_hip.so maxilp:tools/exp/_build/libkfpos_maxilp.so bias0:tools/exp/_build/libkfpos_bias0.so > gpurun_out/libs_ab/log.txt 2>&1
+bash tools/gpu_libs_ab.sh c3 prev:tools/exp/_build/libkfpos_ship_prev.so new:roskfpos_amd/csrc/libkfpos_hip.so pairs:roskfpos_amd/csrc/libkfpos_hip.so:KFPOS_PAIR9=1 > gpurun_out/libs_ab/log.txt 2>&1
 python - <<'PY'
 import json,collections
 d=collections.defaultdict(list)
