@@ -661,6 +661,9 @@ __global__ __launch_bounds__(WAVE) void k_step_imu9(const KArgs a) {
             Scratch sc{nullptr, nullptr, nullptr, WAVE};
             if (has_ranging) sc = stage_epoch_lds<MREAL>(a, lds, lane, t, opaque_uniform(e));
             s = step_imu9<RANGING>(tg, sc, pr, dt, imu, park);
+            if constexpr (!AHEAD) { /* the ranges are staged per epoch above; the next accelerometer sample is not */
+                if (e + 1 < a.n_steps && fresh_imu) fetch_imu<MREAL>(a, opaque_lane(t), opaque_uniform(e + 1), rawi);
+            }
         }
         if (a.traj) { /* the pose a per-epoch caller would have read back (getPose at timeLag 0) */
 #pragma unroll
@@ -1055,13 +1058,15 @@ struct kfpos_handle {
         unsigned char *host = nullptr; /* pinned block: ranges | err | accel | cov | dt | status | pos */
         unsigned char *dev = nullptr;  /* device block, same layout */
         hipEvent_t copied = nullptr, copied2 = nullptr, computed = nullptr, done = nullptr;
+        /* `computed` of the last submission (of ANY slot) whose kernel read this slot's device errorEstimations /
+         * sensor covariance: an upload into those regions waits for it, whichever slot holds the current ones by then */
+        hipEvent_t err_reader = nullptr, cov_reader = nullptr;
         bool busy = false;
     } slot[KFPOS_N_SLOTS];
     size_t so_ranges = 0, so_err = 0, so_accel = 0, so_cov = 0, so_dt = 0, so_status = 0, so_pos = 0, so_bytes = 0;
     hipStream_t s_copy = nullptr, s_copy2 = nullptr, s_comp = nullptr, s_back = nullptr;
     size_t split_bytes = 0;                            /* H2D copies from this size on travel as two halves on two streams */
     int err_slot = -1, cov_slot = -1;                  /* which slot's device block holds the current err / cov */
-    hipEvent_t err_last_use = nullptr, cov_last_use = nullptr; /* `computed` of the last submission that read them */
 };
 
 namespace {
@@ -1361,6 +1366,21 @@ int drain_slots(kfpos_handle *h) {
     return KFPOS_OK;
 }
 
+/* Every entry point runs on its handle's device whatever the calling thread's current device is (a process that
+ * drives one handle per GPU from one thread: kfpos_comm_init_all), and leaves the caller's device as it found it. */
+struct DevScope {
+    int prev = -1;
+    bool switched = false;
+    explicit DevScope(int dev) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DevScope() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    DevScope(const DevScope &) = delete;
+    DevScope &operator=(const DevScope &) = delete;
+};
+
 /* packed index of the stored covariance entry (i, j) */
 inline int pidx(const kfpos_handle *h, int i, int j) {
     if (h->full) return i * h->n + j;
@@ -1413,7 +1433,7 @@ int kfpos_create(const kfpos_config *cfg, kfpos_handle **out) {
         g_err = "no HIP device";
         return KFPOS_ERR_NO_DEVICE;
     }
-    HIPCHK(hipSetDevice(cfg->device));
+    DevScope dev_(cfg->device); /* the caller's current device is left as it was */
     kfpos_handle *h = new (std::nothrow) kfpos_handle();
     if (!h) return KFPOS_ERR_ARG;
     h->cfg = *cfg;
@@ -1557,6 +1577,7 @@ int kfpos_destroy(kfpos_handle *h) {
     void *ptrs[] = {h->d_pos, h->d_vel, h->d_P, h->d_imu_acc, h->d_imu_cov, h->d_flags, h->d_ranges,
                     h->d_err, h->d_accel, h->d_cov, h->d_dt, h->d_out, h->d_status, h->d_latch, h->d_sensor,
                     h->d_stage};
+    DevScope dev_(h->cfg.device);
     (void)hipDeviceSynchronize(); /* nothing of this handle may still be in flight (streaming slots) */
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -1595,6 +1616,7 @@ int kfpos_set_anchors(kfpos_handle *h, const double *xyz, const int32_t *ids, in
 int kfpos_set_init_positions(kfpos_handle *h, const double *xyz) {
     g_err.clear();
     if (!h || !xyz) return KFPOS_ERR_ARG;
+    DevScope dev_(h->cfg.device);
     if (!h->cfg.use_init_pos || h->stepped) return KFPOS_ERR_STATE;
     stage_reset(h);
     if (h->n == 3) { /* ALGORITHM_ML: the seed of every solve */
@@ -1612,6 +1634,7 @@ int kfpos_set_init_positions(kfpos_handle *h, const double *xyz) {
 int kfpos_set_planar(kfpos_handle *h, const kfpos_planar_config *cfg) {
     g_err.clear();
     if (!h || !cfg) return KFPOS_ERR_ARG;
+    DevScope dev_(h->cfg.device);
     if (h->cfg.model != KFPOS_MODEL_PLANAR) return KFPOS_ERR_MODEL;
     if (h->stepped) return KFPOS_ERR_STATE;
     h->planar = *cfg;
@@ -1632,6 +1655,7 @@ int kfpos_step_toa_dev(kfpos_handle *h, const int32_t *range_mm, const void *err
                        double dt_shared, uint32_t *status, void *stream) {
     g_err.clear();
     if (!h || !range_mm || !err_est) return KFPOS_ERR_ARG;
+    DevScope dev_(h->cfg.device);
     if (!h->have_anchors) {
         g_err = "kfpos_set_anchors has not been called (the node drops ranges until the anchors are known, Posgenerator.cpp:92-96)";
         return KFPOS_ERR_STATE;
@@ -1651,6 +1675,7 @@ int kfpos_step_imu_dev(kfpos_handle *h, const void *accel, const void *cov, cons
                        double dt_shared, uint32_t *status, void *stream) {
     g_err.clear();
     if (!h || !accel || !cov) return KFPOS_ERR_ARG;
+    DevScope dev_(h->cfg.device);
     if (h->cfg.model != KFPOS_MODEL_TOA_IMU) return KFPOS_OK; /* KalmanFilterTOA::newIMUMeasurement is empty */
     KArgs a;
     fill_args(h, a);
@@ -1678,6 +1703,7 @@ int kfpos_step_sensor_dev(kfpos_handle *h, int32_t kind, const double *data, con
                           uint32_t *status, void *stream) {
     g_err.clear();
     if (!h || !data || sensor_width(kind) == 0) return KFPOS_ERR_ARG;
+    DevScope dev_(h->cfg.device);
     if (h->cfg.model != KFPOS_MODEL_PLANAR) { /* the empty virtuals of PositionEstimationAlgorithm.h:26-35 */
         if (status) HIPCHK(hipMemsetAsync(status, 0, sizeof(uint32_t) * h->cfg.n_tags, (hipStream_t)stream));
         return KFPOS_OK;
@@ -1699,6 +1725,7 @@ int kfpos_step_toa_imu_dev(kfpos_handle *h, const int32_t *range_mm, const void 
                            uint32_t *status, void *stream) {
     g_err.clear();
     if (!h || !range_mm || !err_est || !accel || !cov) return KFPOS_ERR_ARG;
+    DevScope dev_(h->cfg.device);
     if (h->cfg.model != KFPOS_MODEL_TOA_IMU) return KFPOS_ERR_MODEL;
     if (!h->have_anchors) return KFPOS_ERR_STATE;
     KArgs a;
@@ -1721,6 +1748,7 @@ int kfpos_run_trace_dev(kfpos_handle *h, int32_t n_steps, const int32_t *range_m
                         uint32_t *status, void *stream) {
     g_err.clear();
     if (!h || n_steps < 0 || !range_mm || !err_est || !dt_steps) return KFPOS_ERR_ARG;
+    DevScope dev_(h->cfg.device);
     if (accel && (!cov || h->cfg.model != KFPOS_MODEL_TOA_IMU)) return KFPOS_ERR_MODEL;
     if (!h->have_anchors) return KFPOS_ERR_STATE;
     KArgs a;
@@ -1759,6 +1787,7 @@ static int launch_pose(kfpos_handle *h, double dt_ahead, const double *dt_each, 
                        double *vel, uint32_t *status, void *stream, double *full_x = nullptr,
                        double *full_P = nullptr) {
     if (!h) return KFPOS_ERR_ARG;
+    DevScope dev_(h->cfg.device);
     PoseArgs a;
     a.dt_each = dt_each;
     a.full_x = full_x;
@@ -1811,6 +1840,7 @@ int kfpos_step_toa(kfpos_handle *h, const int32_t *range_mm, const void *err_est
                    int32_t dt_len, uint32_t *status) {
     g_err.clear();
     if (!h || !range_mm || !err_est) return KFPOS_ERR_ARG;
+    DevScope dev_(h->cfg.device);
     if (!h->have_anchors) {
         g_err = "kfpos_set_anchors has not been called (the node drops ranges until the anchors are known, Posgenerator.cpp:92-96)";
         return KFPOS_ERR_STATE;
@@ -1840,6 +1870,7 @@ int kfpos_step_imu(kfpos_handle *h, const void *accel, const void *cov, const do
                    uint32_t *status) {
     g_err.clear();
     if (!h || !accel || !cov) return KFPOS_ERR_ARG;
+    DevScope dev_(h->cfg.device);
     if (h->cfg.model != KFPOS_MODEL_TOA_IMU) {
         if (status) std::memset(status, 0, sizeof(uint32_t) * h->cfg.n_tags);
         return KFPOS_OK;
@@ -1870,6 +1901,7 @@ int kfpos_step_sensor(kfpos_handle *h, int32_t kind, const double *data, const d
     g_err.clear();
     const int C = sensor_width(kind);
     if (!h || !data || C == 0) return KFPOS_ERR_ARG;
+    DevScope dev_(h->cfg.device);
     if (h->cfg.model != KFPOS_MODEL_PLANAR) {
         if (status) std::memset(status, 0, sizeof(uint32_t) * h->cfg.n_tags);
         return KFPOS_OK;
@@ -1935,6 +1967,7 @@ int kfpos_slot_count(const kfpos_handle *h) { return h ? KFPOS_N_SLOTS : 0; }
 int kfpos_slot_acquire(kfpos_handle *h, int32_t slot, kfpos_epoch_slot *out) {
     g_err.clear();
     if (!h || !out || slot < 0 || slot >= KFPOS_N_SLOTS) return KFPOS_ERR_ARG;
+    DevScope dev_(h->cfg.device);
     const int rc = slots_init(h);
     if (rc) return rc;
     auto &sl = h->slot[slot];
@@ -1955,6 +1988,7 @@ int kfpos_slot_acquire(kfpos_handle *h, int32_t slot, kfpos_epoch_slot *out) {
 int kfpos_slot_submit(kfpos_handle *h, int32_t slot, int32_t flags, double dt_shared) {
     g_err.clear();
     if (!h || slot < 0 || slot >= KFPOS_N_SLOTS) return KFPOS_ERR_ARG;
+    DevScope dev_(h->cfg.device);
     if (!h->s_copy || h->slot[slot].busy) {
         g_err = "kfpos_slot_submit: acquire the slot first (kfpos_slot_acquire)";
         return KFPOS_ERR_STATE;
@@ -1989,7 +2023,8 @@ int kfpos_slot_submit(kfpos_handle *h, int32_t slot, int32_t flags, double dt_sh
         second = true;
         return hipMemcpyAsync(sl.dev + off + half, sl.host + off + half, bytes - half, hipMemcpyHostToDevice, h->s_copy2);
     };
-    /* a slot's device copy of err / cov may still be read by a later submission of another slot that reused it */
+    /* a slot's device copy of err / cov may still be read by a later submission of another slot that reused it
+     * (KFPOS_SLOT_REUSE_*) -- also after a third slot has uploaded newer ones in between */
     auto guard = [&](hipEvent_t last_use) -> hipError_t {
         hipError_t e = hipStreamWaitEvent(h->s_copy, last_use, 0);
         return e != hipSuccess ? e : hipStreamWaitEvent(h->s_copy2, last_use, 0);
@@ -2003,8 +2038,8 @@ int kfpos_slot_submit(kfpos_handle *h, int32_t slot, int32_t flags, double dt_sh
         g_err = "KFPOS_SLOT_REUSE_COV before any covariance was submitted";
         return KFPOS_ERR_STATE;
     }
-    if (up_err && h->err_slot == slot && h->err_last_use) HIPCHK(guard(h->err_last_use));
-    if (up_cov && h->cov_slot == slot && h->cov_last_use) HIPCHK(guard(h->cov_last_use));
+    if (up_err && sl.err_reader) HIPCHK(guard(sl.err_reader));
+    if (up_cov && sl.cov_reader) HIPCHK(guard(sl.cov_reader));
     if (up_err && up_cov) { /* the whole block in one go */
         const size_t end = (flags & KFPOS_SLOT_DT_PER_TAG) ? h->so_dt + T * sizeof(double) : h->so_cov + 9 * T * m;
         HIPCHK(h2d(h->so_ranges, end - h->so_ranges));
@@ -2040,8 +2075,8 @@ int kfpos_slot_submit(kfpos_handle *h, int32_t slot, int32_t flags, double dt_sh
     const int rc = launch_step(h, a, h->s_comp);
     if (rc) return rc;
     HIPCHK(hipEventRecord(sl.computed, h->s_comp));
-    if (has_rng) h->err_last_use = sl.computed;
-    if (has_imu) h->cov_last_use = sl.computed;
+    if (has_rng) h->slot[h->err_slot].err_reader = sl.computed;
+    if (has_imu) h->slot[h->cov_slot].cov_reader = sl.computed;
     /* 3. outputs: device -> pinned host, on the return stream */
     HIPCHK(hipStreamWaitEvent(h->s_back, sl.computed, 0));
     /* status words and poses sit side by side in the slot: one copy */
@@ -2056,6 +2091,7 @@ int kfpos_slot_submit(kfpos_handle *h, int32_t slot, int32_t flags, double dt_sh
 int kfpos_slot_wait(kfpos_handle *h, int32_t slot) {
     g_err.clear();
     if (!h || slot < 0 || slot >= KFPOS_N_SLOTS) return KFPOS_ERR_ARG;
+    DevScope dev_(h->cfg.device);
     auto &sl = h->slot[slot];
     if (sl.busy) {
         HIPCHK(hipEventSynchronize(sl.done));
@@ -2067,6 +2103,7 @@ int kfpos_slot_wait(kfpos_handle *h, int32_t slot) {
 int kfpos_get_height(kfpos_handle *h, double *z) {
     g_err.clear();
     if (!h || !z) return KFPOS_ERR_ARG;
+    DevScope dev_(h->cfg.device);
     if (h->cfg.model != KFPOS_MODEL_PLANAR) return KFPOS_ERR_MODEL;
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(z, h->d_pos + 2 * (size_t)h->cfg.n_tags, sizeof(double) * h->cfg.n_tags, hipMemcpyDeviceToHost));
@@ -2076,6 +2113,7 @@ int kfpos_get_height(kfpos_handle *h, double *z) {
 int kfpos_set_height(kfpos_handle *h, const double *z) {
     g_err.clear();
     if (!h || !z) return KFPOS_ERR_ARG;
+    DevScope dev_(h->cfg.device);
     if (h->cfg.model != KFPOS_MODEL_PLANAR) return KFPOS_ERR_MODEL;
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(h->d_pos + 2 * (size_t)h->cfg.n_tags, z, sizeof(double) * h->cfg.n_tags, hipMemcpyHostToDevice));
@@ -2086,6 +2124,7 @@ int kfpos_step_toa_imu(kfpos_handle *h, const int32_t *range_mm, const void *err
                        const void *cov, const double *dt, int32_t dt_len, uint32_t *status) {
     g_err.clear();
     if (!h || !range_mm || !err_est || !accel || !cov) return KFPOS_ERR_ARG;
+    DevScope dev_(h->cfg.device);
     if (h->cfg.model != KFPOS_MODEL_TOA_IMU) return KFPOS_ERR_MODEL;
     if (!h->have_anchors) return KFPOS_ERR_STATE;
     const double *d_dt;
@@ -2119,6 +2158,7 @@ int kfpos_step_toa_imu(kfpos_handle *h, const int32_t *range_mm, const void *err
 static int get_pose_host(kfpos_handle *h, double dt_ahead, const double *dt_each, double *pos, double *cov3x3,
                          double *vel, uint32_t *status) {
     if (!h) return KFPOS_ERR_ARG;
+    DevScope dev_(h->cfg.device);
     const size_t T = h->cfg.n_tags;
     int rc0 = drain_slots(h);
     if (rc0) return rc0;
@@ -2171,6 +2211,7 @@ int kfpos_get_predicted(kfpos_handle *h, const double *dt_ahead, int32_t dt_len,
                         uint32_t *status) {
     g_err.clear();
     if (!h || !dt_ahead || !x || !P || (dt_len != 1 && dt_len != h->cfg.n_tags)) return KFPOS_ERR_ARG;
+    DevScope dev_(h->cfg.device);
     const size_t T = h->cfg.n_tags, n = h->n;
     int rc0 = drain_slots(h);
     if (rc0) return rc0;
@@ -2216,6 +2257,7 @@ int kfpos_get_predicted(kfpos_handle *h, const double *dt_ahead, int32_t dt_len,
 int kfpos_get_state(kfpos_handle *h, double *x, double *P, uint32_t *flags) {
     g_err.clear();
     if (!h) return KFPOS_ERR_ARG;
+    DevScope dev_(h->cfg.device);
     HIPCHK(hipDeviceSynchronize());
     const size_t T = h->cfg.n_tags;
     const int n = h->n;
@@ -2262,6 +2304,7 @@ int kfpos_get_state(kfpos_handle *h, double *x, double *P, uint32_t *flags) {
 int kfpos_set_state(kfpos_handle *h, const double *x, const double *P, const uint32_t *flags) {
     g_err.clear();
     if (!h) return KFPOS_ERR_ARG;
+    DevScope dev_(h->cfg.device);
     HIPCHK(hipDeviceSynchronize());
     const size_t T = h->cfg.n_tags;
     const int n = h->n;
@@ -2318,6 +2361,7 @@ int kfpos_latch_dim(const kfpos_handle *h) {
 int kfpos_get_latch(kfpos_handle *h, double *latch) {
     g_err.clear();
     if (!h) return KFPOS_ERR_ARG;
+    DevScope dev_(h->cfg.device);
     const int L = kfpos_latch_dim(h);
     if (L == 0) return KFPOS_OK;
     if (!latch) return KFPOS_ERR_ARG;
@@ -2345,6 +2389,7 @@ int kfpos_get_latch(kfpos_handle *h, double *latch) {
 int kfpos_set_latch(kfpos_handle *h, const double *latch) {
     g_err.clear();
     if (!h) return KFPOS_ERR_ARG;
+    DevScope dev_(h->cfg.device);
     const int L = kfpos_latch_dim(h);
     if (L == 0) return KFPOS_OK;
     if (!latch) return KFPOS_ERR_ARG;
@@ -2371,12 +2416,14 @@ int kfpos_set_latch(kfpos_handle *h, const double *latch) {
 int kfpos_timing_begin(kfpos_handle *h, void *stream) {
     g_err.clear();
     if (!h) return KFPOS_ERR_ARG;
+    DevScope dev_(h->cfg.device);
     HIPCHK(hipEventRecord(h->ev0, (hipStream_t)stream));
     return KFPOS_OK;
 }
 int kfpos_timing_end(kfpos_handle *h, void *stream, float *elapsed_ms) {
     g_err.clear();
     if (!h || !elapsed_ms) return KFPOS_ERR_ARG;
+    DevScope dev_(h->cfg.device);
     HIPCHK(hipEventRecord(h->ev1, (hipStream_t)stream));
     HIPCHK(hipEventSynchronize(h->ev1));
     HIPCHK(hipEventElapsedTime(elapsed_ms, h->ev0, h->ev1));

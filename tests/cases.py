@@ -38,8 +38,10 @@ class Case:
             r[::3, 2:] = 0
         if s % 23 == 9:
             r[1::4, :] = 0
-        if self.outlier:
+        if self.outlier is True:  # +0.8 m (an absent range turns into a 0.8 m one: kept, the fixtures hold it)
             r[::5, 3] += 800
+        elif self.outlier:        # a number: that many millimetres too long; absent ranges stay absent
+            r[::5, 3] = np.where(r[::5, 3] > 0, r[::5, 3] + int(self.outlier), r[::5, 3])
         return r
 
     def accel_cov(self, w):
@@ -62,6 +64,12 @@ CASES = [
     # 8 anchors every third tag of the s % 11 == 5 epochs has 2 ranges, others 7: ndrop runs through 0..N
     Case("toa6_A8_top1", MODEL_TOA, 8, top_n=1, outlier=True, T=32, S=50),
     Case("toa6_A16_top3", MODEL_TOA, 16, top_n=3, outlier=True, T=32, S=50),
+    # one range 40 / 60 m too long: the leave-one-out and top-N solves take their first Gauss-Newton sweep as "all-ranges
+    # sums minus the dropped anchor's terms" (kfpos_core_toa6.h) -- not the reference's summation order -- and that
+    # subtraction cancels worst exactly when the dropped residual dwarfs the others
+    Case("toa6_A8_ignoreworst_far", MODEL_TOA, 8, ignore_worst=True, outlier=40000, T=32, S=50),
+    Case("toa6_A16_top2_far", MODEL_TOA, 16, top_n=2, outlier=60000, T=32, S=50),
+    Case("toa6_A8_top1_far", MODEL_TOA, 8, top_n=1, outlier=25000, T=32, S=50),
     Case("imu9_A8_fixed", MODEL_TOA_IMU, 8),
     Case("imu9_A8_mlinit", MODEL_TOA_IMU, 8, fixed=False),
     Case("imu9_A8_latched", MODEL_TOA_IMU, 8, imu_every=3, cov_full=True),

@@ -163,13 +163,19 @@ def _torch_trace(w, S, real):
     return r, a, dt, rt, at, et, ct
 
 
-@pytest.mark.parametrize("model,storage", [(0, 0), (1, 0), (1, 1), (1, 2)])
-def test_device_api_and_trace_replay_equal_host_api(model, storage):
+@pytest.mark.parametrize("model,storage,A,generic", [
+    (0, 0, 8, False), (1, 0, 8, False), (1, 1, 8, False), (1, 2, 8, False),
+    # the run-time-anchor-count kernels (epoch staged in LDS per epoch): a multi-epoch launch must fetch every epoch's
+    # accelerometer sample too -- in round 2 it re-fused the launch's first one unless the storage mode was MIXED
+    (1, 0, 12, False), (1, 1, 12, False), (1, 2, 12, False), (1, 0, 8, True), (1, 1, 8, True), (0, 0, 12, False)])
+def test_device_api_and_trace_replay_equal_host_api(model, storage, A, generic, monkeypatch):
     """Device-pointer entry points (component-major, torch-owned HBM) == host-buffer entry points."""
     import torch
     from roskfpos_amd import capi
     from roskfpos_amd.synth import Workload
-    T, A, S = 1000, 8, 12
+    if generic:
+        monkeypatch.setenv("KFPOS_GENERIC_KERNEL", "1")
+    T, S = 1000, 12
     real = np.float32 if storage else np.float64
     w = Workload(T, A)
     r, a, dt, rt, at, et, ct = _torch_trace(w, S, real)
@@ -203,6 +209,8 @@ def test_device_api_and_trace_replay_equal_host_api(model, storage):
     for other in (dev, rep):
         xo, Po, _ = other.get_state()
         assert np.array_equal(xh, xo) and np.array_equal(Ph, Po)
+        if model == 1:  # the sample left latched is the LAST epoch's (lastImuMeasurement, KalmanFilterTOAIMU.cpp:78-89)
+            assert np.array_equal(host.get_latch(), other.get_latch())
     # pose straight into torch memory, component-major
     pos_t = torch.zeros(3, T, dtype=torch.float64, device="cuda:0")
     dev.get_pose_dev(0.05, pos=pos_t, stream=stream)

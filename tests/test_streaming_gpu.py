@@ -130,6 +130,55 @@ def test_slot_api_against_oracle_and_misuse():
     b.close()
 
 
+@pytest.mark.parametrize("model", [0, 1])
+def test_slot_upload_waits_for_readers_of_an_older_upload(model):
+    """Slot 0 uploads errorEstimations (and the sensor covariance), slot 1 re-uses them, slot 2 uploads new ones, then
+    slot 0 is filled and uploaded again while slot 1's kernel -- which reads slot 0's device block -- may still be
+    queued: the upload has to wait for that reader although slot 0 no longer holds the current values (round 2 only
+    guarded the slot that did). Values differ from upload to upload, so a torn read changes the result."""
+    if not has_gpu():
+        pytest.skip("no GPU")
+    from roskfpos_amd import capi
+    T, A, S = 65536, 8, 18
+    w = Workload(T, A)
+    storage = capi.STORE_MIXED if model == 1 else capi.STORE_F32
+    real = np.float32
+    sync, strm = _bank(model, T, w, storage), _bank(model, T, w, storage)
+    NS = strm.lib.kfpos_slot_count(strm._h)
+    assert NS == 3
+    err0, cov0 = w.err_est(real), w.accel_cov(real)
+    cur_err = cur_cov = None
+    views = {}
+    for s in range(S):
+        r, dt, a = _epoch(w, s), w.dt_of(s), w.accel(s, real)
+        upload = s % 3 != 1                 # s = 0 up (slot 0), 1 reuse (slot 1), 2 up (slot 2), 3 up (slot 0), ...
+        if upload:
+            cur_err = (err0 * real(1.0 + 0.25 * (s % 5))).astype(real)
+            cur_cov = (cov0 * real(1.0 + 0.5 * (s % 4))).astype(real)
+        if model == 1:
+            sync.step_toa_imu(r, cur_err, a, cur_cov, dt)
+        else:
+            sync.step_toa(r, cur_err, dt)
+        slot = s % NS
+        v = views[slot] = strm.slot_acquire(slot)
+        v["range_mm"][:] = r.T
+        flags = (capi.SLOT_TOA_IMU if model == 1 else capi.SLOT_TOA) | capi.SLOT_NO_POSE
+        if model == 1:
+            v["accel"][:] = a.T
+        if upload:
+            v["err_est"][:] = cur_err.T
+            if model == 1:
+                v["cov"][:] = cur_cov.T
+        else:
+            flags |= capi.SLOT_REUSE_ERR | (capi.SLOT_REUSE_COV if model == 1 else 0)
+        strm.slot_submit(slot, flags, dt)
+    xs, Ps, _ = sync.get_state()
+    xt, Pt, _ = strm.get_state()
+    assert np.array_equal(xs, xt) and np.array_equal(Ps, Pt)
+    sync.close()
+    strm.close()
+
+
 @pytest.mark.parametrize("model,A", [(0, 8), (0, 16), (1, 8), (0, 5)])
 def test_small_bank_mapped_block_equals_staged_path(model, A):
     if not has_gpu():
