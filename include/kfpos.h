@@ -34,6 +34,7 @@ extern "C" {
 #define KFPOS_ERR_NO_DEVICE 3 /* no usable gfx950 device */
 #define KFPOS_ERR_MODEL     4 /* call not defined for this handle's model */
 #define KFPOS_ERR_STATE     5 /* e.g. anchors not set yet (Posgenerator.cpp:92-96 drops ranges until then) */
+#define KFPOS_ERR_COMM      6 /* an RCCL call failed, or librccl could not be opened; kfpos_last_error() has the text */
 
 /* ---- models: the `algorithm` launch parameter (node_pos.cpp:48-58) ---- */
 #define KFPOS_MODEL_TOA     0 /* ALGORITHM_KF_TOA     -> KalmanFilterTOA, 6 states p,v */
@@ -301,6 +302,68 @@ int kfpos_run_trace_dev(kfpos_handle *h, int32_t n_steps,
                         const void *accel, int64_t stride_accel,
                         const void *cov, int64_t stride_cov,
                         const double *dt_steps, double *trajectory, uint32_t *status, void *stream);
+
+/* ---- multi-GPU: contiguous tag shards + ONE collective, the RCCL all-gather of poses ----
+ * The reference runs one filter in one process (node_pos.cpp:176-181) and has no counterpart. Here a node that serves
+ * more tags than one GPU holds cuts the batch into contiguous ranges, one handle per GPU; the filters never talk to each
+ * other, and what is published -- the pose of EVERY tag (Posgenerator.cpp:541-548, batched) -- is brought together by one
+ * ncclAllGather per epoch (or per launch of K epochs) over xGMI, on a side stream, double-buffered, so that it overlaps
+ * the next epoch's compute. librccl is opened on first use; a process that never calls kfpos_comm_* does not load it.
+ *
+ * One process per GPU (MPI / a launcher of your own / torchrun):
+ *     rank 0:     kfpos_comm_unique_id(id);  ...ship the 128 bytes to every rank by whatever you bootstrap with...
+ *     every rank: kfpos_comm_create(world, rank, id, device, &comm);
+ *                 kfpos_comm_set_total(comm, total_tags, &lo, &hi);   -> this rank's handle holds tags [lo, hi)
+ *                 per epoch: kfpos_step_*_dev(h, ...); kfpos_allgather_poses(h, comm, NULL, 3, pos_all, stream);
+ *                 before reading pos_all: kfpos_comm_wait(comm, stream)  (or kfpos_comm_sync(comm) on the host)
+ * One process driving n GPUs from one thread:
+ *     kfpos_comm_create_all(n, devices, comms);  then kfpos_allgather_poses_multi(...) once per epoch for all of them.
+ */
+#define KFPOS_COMM_ID_BYTES 128 /* sizeof(ncclUniqueId) */
+typedef struct kfpos_comm kfpos_comm;
+
+/* Contiguous shard [lo, hi) of `rank` out of `world`: sizes differ by at most one tag, the first total % world ranks
+ * hold the extra one. Pure host arithmetic (no GPU, no RCCL). */
+int kfpos_shard_range(int64_t total_tags, int32_t world, int32_t rank, int64_t *lo, int64_t *hi);
+
+/* ncclGetUniqueId: 128 bytes that rank 0 creates and every rank passes to kfpos_comm_create. */
+int kfpos_comm_unique_id(void *id_out);
+/* ncclCommInitRank on `device` (collective: returns when all `world` ranks have called it). */
+int kfpos_comm_create(int32_t world, int32_t rank, const void *unique_id, int32_t device, kfpos_comm **out);
+/* ncclCommInitAll: n communicators of one clique for one process; devices = NULL means 0..n-1. out: n pointers. */
+int kfpos_comm_create_all(int32_t n_devices, const int32_t *devices, kfpos_comm **out);
+int kfpos_comm_destroy(kfpos_comm *c);
+int kfpos_comm_world(const kfpos_comm *c);
+int kfpos_comm_rank(const kfpos_comm *c);
+/* The size of the whole batch; fixes this rank's shard (returned in lo / hi, may be NULL) and the padded block size of
+ * the collective. Call before the first gather, on every rank with the same total (>= world). */
+int kfpos_comm_set_total(kfpos_comm *c, int64_t total_tags, int64_t *lo, int64_t *hi);
+
+/* All-gather of pose blocks (device pointers, component-major, double):
+ *   pos_local  [rows][t_local] this rank's block, or NULL with rows = 3 for the handle's current positions (what
+ *              getPose at timeLag 0 returns for every tag of the shard); rows = 3 for one epoch, 3 K for the K epochs
+ *              of a kfpos_run_trace_dev trajectory. It is copied on `stream` before the call returns to the caller,
+ *              so it may be overwritten by later work on `stream` at once
+ *   pos_all    [rows][total_tags] in global tag order, written on the communicator's side stream: valid after
+ *              kfpos_comm_wait (device-side: `stream` waits for the last gather) or kfpos_comm_sync (host blocks)
+ *   h          the shard's handle (checked against the communicator's shard size and device), or NULL when pos_local is given
+ * Unequal shards are padded to the largest inside the call (an all-gather wants equal contributions) and the padding
+ * is dropped again when pos_all is assembled. Two gathers may be in flight: the third waits for the first. */
+int kfpos_allgather_poses(kfpos_handle *h, kfpos_comm *c, const double *pos_local, int32_t rows, double *pos_all,
+                          void *stream);
+/* The same for n communicators of one process (kfpos_comm_create_all) in ONE RCCL group; arrays of n entries;
+ * handles, pos_local and streams may be NULL (= all NULL). */
+int kfpos_allgather_poses_multi(int32_t n, kfpos_handle *const *handles, kfpos_comm *const *comms,
+                                const double *const *pos_local, int32_t rows, double *const *pos_all,
+                                void *const *streams);
+int kfpos_comm_wait(kfpos_comm *c, void *stream);
+int kfpos_comm_sync(kfpos_comm *c);
+/* The assembly step alone, for a caller that gathers with a collective of its own (torch.distributed, MPI):
+ * staged [world][rows][t_pad] (t_pad = largest shard of kfpos_shard_range) -> out [rows][total_tags]. */
+int kfpos_assemble_poses_dev(int32_t world, int32_t rows, int64_t total_tags, const double *staged, double *out,
+                             int32_t device, void *stream);
+/* NCCL version code of the RCCL that was opened (e.g. 22707), 0 if none could be */
+int kfpos_comm_backend_version(void);
 
 /* ---- diagnostics ---- */
 const char *kfpos_last_error(void);  /* thread-local detail of the last error (HIP failures, rejected configurations, calls out of sequence) */

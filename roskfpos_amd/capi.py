@@ -34,7 +34,12 @@ EXPORTS = [
     "kfpos_set_planar", "kfpos_step_sensor", "kfpos_step_sensor_dev", "kfpos_get_height", "kfpos_set_height",
     "kfpos_latch_dim", "kfpos_get_latch", "kfpos_set_latch",
     "kfpos_slot_count", "kfpos_slot_acquire", "kfpos_slot_submit", "kfpos_slot_wait",
+    "kfpos_shard_range", "kfpos_comm_unique_id", "kfpos_comm_create", "kfpos_comm_create_all", "kfpos_comm_destroy",
+    "kfpos_comm_world", "kfpos_comm_rank", "kfpos_comm_set_total", "kfpos_allgather_poses",
+    "kfpos_allgather_poses_multi", "kfpos_comm_wait", "kfpos_comm_sync", "kfpos_assemble_poses_dev",
+    "kfpos_comm_backend_version",
 ]
+COMM_ID_BYTES = 128
 SLOT_TOA, SLOT_IMU, SLOT_TOA_IMU = 0, 1, 2
 SLOT_DT_PER_TAG, SLOT_REUSE_ERR, SLOT_REUSE_COV, SLOT_NO_POSE = 0x100, 0x200, 0x400, 0x800
 
@@ -127,6 +132,21 @@ def load():
     sig("kfpos_slot_wait", [vp, i32])
     sig("kfpos_timing_begin", [vp, vp])
     sig("kfpos_timing_end", [vp, vp, C.POINTER(C.c_float)])
+    i64 = C.c_int64
+    sig("kfpos_shard_range", [i64, i32, i32, C.POINTER(i64), C.POINTER(i64)])
+    sig("kfpos_comm_unique_id", [vp])
+    sig("kfpos_comm_create", [i32, i32, vp, i32, C.POINTER(vp)])
+    sig("kfpos_comm_create_all", [i32, vp, C.POINTER(vp)])
+    sig("kfpos_comm_destroy", [vp])
+    sig("kfpos_comm_world", [vp])
+    sig("kfpos_comm_rank", [vp])
+    sig("kfpos_comm_set_total", [vp, i64, C.POINTER(i64), C.POINTER(i64)])
+    sig("kfpos_allgather_poses", [vp, vp, vp, i32, vp, vp])
+    sig("kfpos_allgather_poses_multi", [i32, vp, vp, vp, i32, vp, vp])
+    sig("kfpos_comm_wait", [vp, vp])
+    sig("kfpos_comm_sync", [vp])
+    sig("kfpos_assemble_poses_dev", [i32, i32, i64, vp, vp, i32, vp])
+    sig("kfpos_comm_backend_version", [])
     L.kfpos_last_error.restype = C.c_char_p
     L.kfpos_strerror.restype = C.c_char_p
     sig("kfpos_strerror", [C.c_int])
@@ -378,3 +398,98 @@ class KfposBank:
         ms = C.c_float()
         self._chk(self.lib.kfpos_timing_end(self._h, _ptr(stream), C.byref(ms)))
         return float(ms.value)
+
+
+# ---- multi-GPU: the RCCL pose all-gather behind the C ABI (include/kfpos.h: kfpos_comm_*) ----
+def _chk_lib(lib, rc):
+    if rc != 0:
+        msg = lib.kfpos_strerror(rc).decode()
+        detail = lib.kfpos_last_error().decode()
+        raise KfposError(msg + (": " + detail if detail else ""))
+
+
+def shard_range(total_tags: int, world: int, rank: int):
+    """kfpos_shard_range: contiguous [lo, hi) of `rank`; host arithmetic only."""
+    lo, hi = C.c_int64(), C.c_int64()
+    lib = load()
+    _chk_lib(lib, lib.kfpos_shard_range(total_tags, world, rank, C.byref(lo), C.byref(hi)))
+    return lo.value, hi.value
+
+
+def comm_unique_id() -> bytes:
+    """ncclGetUniqueId through the library: rank 0 makes it, every rank gets the same 128 bytes."""
+    lib = load()
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    _chk_lib(lib, lib.kfpos_comm_unique_id(buf))
+    return buf.raw
+
+
+def assemble_poses_dev(world, rows, total_tags, staged, out, device=0, stream=None):
+    """[world][rows][t_pad] gathered by any collective -> [rows][total] in global tag order (device tensors)."""
+    lib = load()
+    _chk_lib(lib, lib.kfpos_assemble_poses_dev(world, rows, total_tags, _ptr(staged), _ptr(out), device, _ptr(stream)))
+
+
+class KfposComm:
+    """One rank's end of the pose all-gather (kfpos_comm): RCCL communicator + side stream + two buffer sets."""
+
+    def __init__(self, world, rank, unique_id: bytes, device=0, _handle=None):
+        self.lib = load()
+        self._c = None
+        if _handle is not None:
+            self._c = _handle
+        else:
+            assert len(unique_id) == COMM_ID_BYTES
+            c = C.c_void_p()
+            _chk_lib(self.lib, self.lib.kfpos_comm_create(world, rank, unique_id, device, C.byref(c)))
+            self._c = c
+        self.world, self.rank, self.device = self.lib.kfpos_comm_world(self._c), self.lib.kfpos_comm_rank(self._c), device
+        self.lo = self.hi = None
+
+    @classmethod
+    def create_all(cls, devices):
+        """One process, several GPUs (ncclCommInitAll): a list of communicators, one per device."""
+        lib = load()
+        n = len(devices)
+        devs = (C.c_int32 * n)(*devices)
+        out = (C.c_void_p * n)()
+        _chk_lib(lib, lib.kfpos_comm_create_all(n, devs, out))
+        return [cls(n, i, b"", devices[i], _handle=C.c_void_p(out[i])) for i in range(n)]
+
+    def set_total(self, total_tags: int):
+        lo, hi = C.c_int64(), C.c_int64()
+        _chk_lib(self.lib, self.lib.kfpos_comm_set_total(self._c, total_tags, C.byref(lo), C.byref(hi)))
+        self.lo, self.hi, self.total = lo.value, hi.value, total_tags
+        return self.lo, self.hi
+
+    def allgather(self, pos_all, pos_local=None, rows=3, bank=None, stream=None):
+        """pos_local [rows][t_local] (or the bank's current positions) -> pos_all [rows][total]; asynchronous."""
+        _chk_lib(self.lib, self.lib.kfpos_allgather_poses(bank._h if bank is not None else None, self._c,
+                                                          _ptr(pos_local), rows, _ptr(pos_all), _ptr(stream)))
+
+    def wait(self, stream=None):
+        _chk_lib(self.lib, self.lib.kfpos_comm_wait(self._c, _ptr(stream)))
+
+    def sync(self):
+        _chk_lib(self.lib, self.lib.kfpos_comm_sync(self._c))
+
+    def close(self):
+        if self._c:
+            self.lib.kfpos_comm_destroy(self._c)
+            self._c = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def allgather_poses_multi(comms, pos_all, pos_local=None, rows=3, banks=None, streams=None):
+    """kfpos_allgather_poses_multi: the gathers of all communicators of one process in one RCCL group."""
+    lib = load()
+    n = len(comms)
+    arr = lambda xs: (C.c_void_p * n)(*[_ptr(x) for x in xs]) if xs is not None else None  # noqa: E731
+    _chk_lib(lib, lib.kfpos_allgather_poses_multi(
+        n, arr([b._h.value for b in banks]) if banks is not None else None, arr([c._c.value for c in comms]),
+        arr(pos_local), rows, arr(pos_all), arr(streams)))

@@ -55,15 +55,18 @@ namespace kfpos_chain {
 #include "kfpos_core.h"
 }
 #pragma clang fp contract(on)
-#include "../../include/kfpos.h"
+#include "kfpos_internal.h"
+
+std::string &kfpos_error_text() {
+    thread_local std::string text;
+    return text;
+}
 
 namespace {
 
 using namespace kfpos;
 
 constexpr int WAVE = 64; /* lanes per workgroup = one wavefront */
-#define KFPOS_TRACE_CHUNK 128 /* epochs per multi-epoch launch (their dt values travel in the kernel arguments) */
-#define KFPOS_N_SLOTS 3      /* streaming host API: one slot being filled, one on the bus, one computing / returning */
 
 enum StepMode : int { MODE_TOA = 0, MODE_IMU_ONLY = 1, MODE_FUSED = 2 };
 
@@ -1001,7 +1004,7 @@ __global__ __launch_bounds__(256) void k_cols_to_rows(const E *src, E *dst, int 
 }
 
 /* ------------------------------------------------------------------ host side */
-thread_local std::string g_err;
+#define g_err (kfpos_error_text())
 
 #define HIPCHK(expr)                                                                              \
     do {                                                                                          \
@@ -1014,60 +1017,6 @@ thread_local std::string g_err;
 
 } // namespace
 
-struct kfpos_handle {
-    kfpos_config cfg;
-    int n;        /* state dimension */
-    int full;     /* COV_FULL layout: 6-state with ML initialisation (non-symmetric P) */
-    int psz;      /* stored covariance entries per tag */
-    int rsz;      /* bytes per stored covariance entry */
-    int msz;      /* sizeof(kfpos_real): bytes per measurement element */
-    int A;        /* anchors set */
-    bool have_anchors, stepped;
-    int trace_chunk;    /* epochs per launch in kfpos_run_trace_dev (KFPOS_TRACE_CHUNK_STEPS, 1..128) */
-    bool force_generic; /* KFPOS_GENERIC_KERNEL=1: always the LDS-staged kernel (A/B measurements, tests) */
-    bool two_waves;     /* n_tags / 64 exceeds the device's SIMD count (KFPOS_ONE_WAVE_BUILD=1: never) */
-    bool pair9;         /* 9-state bank: iekf9_pairs for the tail of the gain iteration; KFPOS_PAIR9=1 enables (built, bit-identical, measured: no gain worth having -- DESIGN 6a) */
-    bool coop;          /* small plain 6-state bank: one tag per 8 lanes (k_step_toa6_coop); KFPOS_NO_COOP=1 disables */
-    double anchors[KFPOS_MAX_ANCHORS * 3];
-    /* device state */
-    double *d_pos = nullptr;
-    double *d_vel = nullptr;
-    void *d_P = nullptr, *d_imu_acc = nullptr, *d_imu_cov = nullptr;
-    uint32_t *d_flags = nullptr;
-    /* staging for the host-buffer API */
-    int32_t *d_ranges = nullptr;
-    void *d_err = nullptr, *d_accel = nullptr, *d_cov = nullptr;
-    double *d_dt = nullptr, *d_out = nullptr; /* d_out: [15][T] doubles for pose results */
-    uint32_t *d_status = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    /* planar filter */
-    kfpos_planar_config planar = {};
-    bool planar_sensors = false; /* a PX4Flow / IMU / magnetometer / compass sample has been fed: latches are live */
-    double *d_latch = nullptr;   /* [15][T] */
-    double *d_sensor = nullptr;  /* [24][T] staging of one sensor sample */
-    /* row-major staging area of the host-buffer API: one region per array of a call (bump-allocated) */
-    unsigned char *d_stage = nullptr;
-    size_t stage_cap = 0, stage_used = 0;
-    /* small banks (the single-tag adaptor objects, test banks): ONE host-pinned, device-mapped block holds every
-     * input and output of a host-API call in component-major form; the kernels read and write it in place over the
-     * bus, so a call is "turn the layout on the CPU, launch, synchronise" -- no hipMemcpy, no layout kernels */
-    unsigned char *sm_h = nullptr, *sm_d = nullptr;
-    size_t sm_ranges = 0, sm_err = 0, sm_accel = 0, sm_cov = 0, sm_dt = 0, sm_sensor = 0, sm_status = 0, sm_out = 0;
-    /* streaming host API: KFPOS_N_SLOTS slots of pinned host + device buffers, three streams (kfpos_slot_*) */
-    struct Slot {
-        unsigned char *host = nullptr; /* pinned block: ranges | err | accel | cov | dt | status | pos */
-        unsigned char *dev = nullptr;  /* device block, same layout */
-        hipEvent_t copied = nullptr, copied2 = nullptr, computed = nullptr, done = nullptr;
-        /* `computed` of the last submission (of ANY slot) whose kernel read this slot's device errorEstimations /
-         * sensor covariance: an upload into those regions waits for it, whichever slot holds the current ones by then */
-        hipEvent_t err_reader = nullptr, cov_reader = nullptr;
-        bool busy = false;
-    } slot[KFPOS_N_SLOTS];
-    size_t so_ranges = 0, so_err = 0, so_accel = 0, so_cov = 0, so_dt = 0, so_status = 0, so_pos = 0, so_bytes = 0;
-    hipStream_t s_copy = nullptr, s_copy2 = nullptr, s_comp = nullptr, s_back = nullptr;
-    size_t split_bytes = 0;                            /* H2D copies from this size on travel as two halves on two streams */
-    int err_slot = -1, cov_slot = -1;                  /* which slot's device block holds the current err / cov */
-};
 
 namespace {
 
@@ -1366,20 +1315,7 @@ int drain_slots(kfpos_handle *h) {
     return KFPOS_OK;
 }
 
-/* Every entry point runs on its handle's device whatever the calling thread's current device is (a process that
- * drives one handle per GPU from one thread: kfpos_comm_init_all), and leaves the caller's device as it found it. */
-struct DevScope {
-    int prev = -1;
-    bool switched = false;
-    explicit DevScope(int dev) {
-        if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
-    }
-    ~DevScope() {
-        if (switched) (void)hipSetDevice(prev);
-    }
-    DevScope(const DevScope &) = delete;
-    DevScope &operator=(const DevScope &) = delete;
-};
+using DevScope = KfposDevScope; /* kfpos_internal.h */
 
 /* packed index of the stored covariance entry (i, j) */
 inline int pidx(const kfpos_handle *h, int i, int j) {
@@ -1402,6 +1338,7 @@ const char *kfpos_strerror(int code) {
     case KFPOS_ERR_NO_DEVICE: return "no usable GPU";
     case KFPOS_ERR_MODEL: return "call not defined for this model";
     case KFPOS_ERR_STATE: return "call out of sequence";
+    case KFPOS_ERR_COMM: return "RCCL error";
     default: return "unknown error";
     }
 }

@@ -43,17 +43,39 @@ def env_world():
     return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
 
 
+def default_engine(device) -> str:
+    """Which implementation exchanges the poses: "cabi" = the library's own RCCL communicator behind the C ABI
+    (kfpos_allgather_poses: what a C++ node uses too), "torch" = torch.distributed's all_gather_into_tensor. The C ABI
+    needs one GPU per rank and RCCL, so gloo runs (CPU tests, rehearsals of several ranks on one card) use torch.
+    KFPOS_GATHER_ENGINE=torch|cabi overrides."""
+    import torch
+    import torch.distributed as dist
+    forced = os.environ.get("KFPOS_GATHER_ENGINE")
+    if forced in ("torch", "cabi"):
+        return forced
+    if torch.device(device).type != "cuda":
+        return "torch"
+    if dist.is_initialized() and dist.get_world_size() > 1 and dist.get_backend() != "nccl":
+        return "torch"
+    return "cabi" if (dist.is_initialized() and dist.get_world_size() > 1) else "torch"
+
+
 class PoseGather:
-    """All-gather of per-rank pose blocks [rows][t_local] -> [world][rows][t_pad], double-buffered.
+    """All-gather of per-rank pose blocks [rows][t_local] -> every rank holds [rows][T_total], double-buffered.
 
     rows = 3 for one epoch's poses, K*3 for the poses of a K-epoch launch. `sizes` are the shard sizes of all
-    ranks (shard_sizes()); they may differ: buffers are padded to t_pad = max(sizes), assemble() returns the
-    [rows][sum(sizes)] array in global tag order. Works with any torch.distributed backend: nccl (= RCCL) on
-    GPUs, gloo on CPU tensors (tests), gloo with GPU tensors staged through the host (rehearsals of the N > 1
-    path on one card).
+    ranks (shard_sizes()); they may differ by one tag.
+
+    engine "cabi": kfpos_allgather_poses of the library (RCCL communicator, side stream, padding and assembly inside
+    the call; include/kfpos.h) -- the path a C++ node takes. gather() returns the assembled [rows][T_total] tensor.
+    engine "torch": torch.distributed with any backend -- nccl (= RCCL) on GPUs, gloo on CPU tensors (tests), gloo
+    with GPU tensors staged through the host (rehearsals of the N > 1 path on one card). Buffers are padded to
+    t_pad = max(sizes); gather() returns [world][rows][t_pad] and assemble() cuts the padding away.
+    Either way: buffer() -> fill -> gather() -> wait() -> assemble(result) is [rows][T_total] in global tag order.
     """
 
-    def __init__(self, t_local: int, device, dtype=None, overlap: bool = True, rows: int = 3, sizes=None):
+    def __init__(self, t_local: int, device, dtype=None, overlap: bool = True, rows: int = 3, sizes=None,
+                 engine: str = None):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -64,22 +86,53 @@ class PoseGather:
             raise ValueError(f"sizes {self.sizes} do not describe this rank's shard of {t_local} tags")
         self.t_local, self.rows = t_local, rows
         self.t_pad = max(self.sizes)
+        self.total = sum(self.sizes)
         dtype = dtype or torch.float64
+        self.cuda = torch.device(device).type == "cuda"
+        self.engine = engine or default_engine(device)
+        self.k = 0
+        self.count = 0  # collectives issued
+        self.comm = None
+        if self.engine == "cabi":
+            if not self.cuda or dtype != torch.float64:
+                raise ValueError("the C-ABI gather exchanges f64 poses resident in HBM")
+            self._init_cabi(device)
+            return
         self.local = [torch.zeros(rows, self.t_pad, dtype=dtype, device=device) for _ in range(2)]
         # concatenation form [world*rows][t_pad] (what every backend accepts); handed out as [world][rows][t_pad]
         self.flat = [torch.zeros(self.world * rows, self.t_pad, dtype=dtype, device=device) for _ in range(2)]
         self.full = [f.view(self.world, rows, self.t_pad) for f in self.flat]
-        self.cuda = torch.device(device).type == "cuda"
         # gloo has no device collectives: stage through the host (rehearsals of the N>1 path on one card)
         self.host_staged = self.cuda and dist.is_initialized() and dist.get_backend() == "gloo"
         self.overlap = overlap and self.cuda and not self.host_staged
         if self.cuda:
-            self.comm = torch.cuda.Stream(device=device) if self.overlap else None
+            self.side = torch.cuda.Stream(device=device) if self.overlap else None
             self.ready = [torch.cuda.Event() for _ in range(2)]
             self.done = [torch.cuda.Event() for _ in range(2)]
             self.used = [False, False]
-        self.k = 0
-        self.count = 0  # collectives issued
+
+    # ---- engine "cabi" ----
+    def _init_cabi(self, device):
+        from . import capi
+        torch, dist = self.torch, self.dist
+        dev = torch.device(device)
+        index = dev.index if dev.index is not None else torch.cuda.current_device()
+        if self.sizes != shard_sizes(self.total, self.world):
+            raise ValueError("the C-ABI gather shards by kfpos_shard_range; these sizes are something else")
+        uid = [capi.comm_unique_id() if self.rank == 0 else None]
+        if self.world > 1:  # ship rank 0's ncclUniqueId over the process group that is already up
+            dist.broadcast_object_list(uid, src=0, device=dev)
+        self.comm = capi.KfposComm(self.world, self.rank, uid[0], device=index)
+        lo, hi = self.comm.set_total(self.total)
+        assert hi - lo == self.t_local and (lo, hi) == shard_range(self.total, self.world, self.rank)
+        # tight [rows][t_local] blocks to fill when the caller has no contiguous source of its own
+        self.local = [torch.zeros(self.rows, self.t_local, dtype=torch.float64, device=device) for _ in range(2)]
+        self.out = [torch.zeros(self.rows, self.total, dtype=torch.float64, device=device) for _ in range(2)]
+
+    def close(self):
+        if self.comm is not None:
+            self.comm.close()
+            self.comm = None
 
     @property
     def uniform(self) -> bool:
@@ -87,44 +140,63 @@ class PoseGather:
         return min(self.sizes) == self.t_pad
 
     def buffer(self):
-        """Local block to fill for the next gather, [rows][t_pad] (columns >= t_local are padding); waits until
-        the previous gather out of the same buffer has drained."""
+        """Local block to fill for the next gather, [rows][t_pad] (columns >= t_local are padding; engine "cabi":
+        [rows][t_local]); waits until the previous gather out of the same buffer has drained."""
         b = self.k & 1
-        if self.overlap and self.used[b]:
+        if self.engine == "torch" and self.overlap and self.used[b]:
             self.torch.cuda.current_stream().wait_event(self.done[b])
         return self.local[b]
 
-    def gather(self):
-        """Exchange the buffer handed out by buffer(); returns the [world][rows][t_pad] result tensor
-        (valid after wait())."""
+    def gather(self, src=None, rows=None):
+        """Exchange the buffer handed out by buffer() -- or, engine "cabi", a contiguous [rows][t_local] device block
+        of the caller's (no staging copy: the library packs it on the current stream before it returns). Returns the
+        result tensor, valid after wait(): [world][rows][t_pad] (torch) or the assembled [rows][T_total] (cabi)."""
         b = self.k & 1
         self.k += 1
         self.count += 1
+        if self.engine == "cabi":
+            rows = self.rows if rows is None else rows
+            if src is None:
+                src = self.local[b]
+            elif not (src.is_contiguous() and src.numel() == rows * self.t_local):
+                raise ValueError("src must be a contiguous [rows][t_local] block")
+            # the pack runs on torch's current stream, behind whatever produced src; the collective and the assembly on
+            # the communicator's side stream; the third gather in flight waits for the first (inside the call)
+            self.comm.allgather(self.out[b], pos_local=src, rows=rows,
+                                stream=self.torch.cuda.current_stream().cuda_stream)
+            return self.out[b][:rows]
+        if src is not None:
+            self.local[b][:src.shape[0], :self.t_local].copy_(src.reshape(-1, self.t_local), non_blocking=True)
         if self.world == 1:
             self.full[b][0].copy_(self.local[b])
             return self.full[b]
         if self.overlap:
             self.ready[b].record(self.torch.cuda.current_stream())
-            with self.torch.cuda.stream(self.comm):
-                self.comm.wait_event(self.ready[b])
+            with self.torch.cuda.stream(self.side):
+                self.side.wait_event(self.ready[b])
                 self.dist.all_gather_into_tensor(self.flat[b], self.local[b])
-                self.done[b].record(self.comm)
+                self.done[b].record(self.side)
             self.used[b] = True
         elif self.host_staged:
-            src = self.local[b].cpu()
-            dst = self.torch.zeros(self.flat[b].shape, dtype=src.dtype)
-            self.dist.all_gather_into_tensor(dst, src)
+            src_h = self.local[b].cpu()
+            dst = self.torch.zeros(self.flat[b].shape, dtype=src_h.dtype)
+            self.dist.all_gather_into_tensor(dst, src_h)
             self.flat[b].copy_(dst)
         else:
             self.dist.all_gather_into_tensor(self.flat[b], self.local[b])
         return self.full[b]
 
     def wait(self):
-        if self.overlap:
-            self.torch.cuda.current_stream().wait_stream(self.comm)
+        """the current stream waits for the gathers issued so far"""
+        if self.engine == "cabi":
+            self.comm.wait(self.torch.cuda.current_stream().cuda_stream)
+        elif self.overlap:
+            self.torch.cuda.current_stream().wait_stream(self.side)
 
     def assemble(self, full):
-        """[world][rows][t_pad] -> [rows][T_total] in global tag order (padding columns dropped)."""
+        """gather()'s result -> [rows][T_total] in global tag order (padding columns dropped)."""
+        if full.dim() == 2:  # engine "cabi": assembled inside the call
+            return full
         if self.uniform:
             return full.permute(1, 0, 2).reshape(self.rows, self.world * self.t_pad)
         return self.torch.cat([full[r, :, :n] for r, n in enumerate(self.sizes)], dim=1)
@@ -161,7 +233,7 @@ class ShardedReplay:
     """
 
     def __init__(self, bank, n_tags_total: int, device, gather_mode: str = "launch", epochs_per_launch: int = 25,
-                 stream=None):
+                 stream=None, engine: str = None, gather: "PoseGather" = None):
         import torch
         import torch.distributed as dist
         if gather_mode not in GATHER_MODES:
@@ -180,7 +252,12 @@ class ShardedReplay:
         self.gather = None
         if gather_mode != "none":
             rows = 3 * self.E if gather_mode == "trajectory" else 3
-            self.gather = PoseGather(self.T, device, rows=rows, sizes=self.sizes)
+            if gather is not None:  # a communicator is worth keeping: the caller shares one between replays
+                if gather.rows != rows or gather.sizes != self.sizes:
+                    raise ValueError("the PoseGather passed in was made for another block shape")
+                self.gather = gather
+            else:
+                self.gather = PoseGather(self.T, device, rows=rows, sizes=self.sizes, engine=engine)
 
     def run(self, trace, s0: int, n: int, on_gathered=None):
         """Epochs [s0, s0 + n) of `trace` (dict: ranges, err, dts, traj, and accel / cov for the 9-state filter).
@@ -204,9 +281,12 @@ class ShardedReplay:
                 else:
                     blocks = [(s, m)]
                 for first, cnt in blocks:
-                    buf = g.buffer()
-                    buf[:3 * cnt, :T].copy_(traj[first:first + cnt].reshape(3 * cnt, T), non_blocking=True)
-                    full = g.gather()
+                    if g.engine == "cabi":  # the trajectory block itself is the contiguous [3 cnt][T] source
+                        full = g.gather(src=traj[first:first + cnt], rows=3 * cnt)
+                    else:
+                        buf = g.buffer()
+                        buf[:3 * cnt, :T].copy_(traj[first:first + cnt].reshape(3 * cnt, T), non_blocking=True)
+                        full = g.gather()
                     if on_gathered is not None:
                         g.wait()
                         if g.cuda:

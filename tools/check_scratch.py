@@ -26,11 +26,11 @@ def disassemble(lib):
         local = os.path.join(tmp, "lib.so")
         shutil.copy(lib, local)
         subprocess.run([OBJDUMP, "--offloading", local], check=True, capture_output=True, cwd=tmp)
-        cos = [f for f in os.listdir(tmp) if "gfx950" in f]
+        cos = sorted(f for f in os.listdir(tmp) if "gfx950" in f)  # one code object per translation unit
         if not cos:
             raise SystemExit("no gfx950 code object in " + lib)
-        return subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", os.path.join(tmp, cos[0])], check=True,
-                              capture_output=True, text=True).stdout
+        return "\n".join(subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", os.path.join(tmp, co)], check=True,
+                                        capture_output=True, text=True).stdout for co in cos)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
