@@ -68,7 +68,9 @@ extern "C" {
 #define KFPOS_ST_NOT_STARTED    0x10u /* getPose() == false: no measurement yet (KalmanFilterTOA.cpp:442-447) */
 #define KFPOS_ST_NONFINITE      0x20u /* state not finite after the call */
 #define KFPOS_ST_SKIPPED        0x40u /* dt < 0 was passed for this tag: no estimator call, filter untouched */
-#define KFPOS_ST_GAIN_ITERS(s)  (((s) >> 8) & 0xffu)  /* IEKF gain iterations (KalmanFilterTOA.cpp:293-324) */
+#define KFPOS_ST_GAIN_ITERS(s)  (((s) >> 8) & 0xffu)  /* IEKF gain iterations (KalmanFilterTOA.cpp:293-324); KFPOS_MODEL_ML with
+                                                         top_n > 0: Gauss-Newton iterations of the solve that ranks the
+                                                         residuals (estimatePositionIgnoreN's first, MLLocation.cpp:318) */
 #define KFPOS_ST_ML_ITERS(s)    (((s) >> 16) & 0xffu) /* ML Gauss-Newton iterations, saturating (MLLocation.cpp:168-225) */
 #define KFPOS_ST_IGNORED(s)     ((int)(((s) >> 24) & 0xffu) - 1) /* index among this epoch's >0 ranges of the anchor the
                                                                     leave-one-out heuristic dropped, -1 if none */

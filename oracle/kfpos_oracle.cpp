@@ -716,7 +716,10 @@ unsigned ml_estimator(const Params &pr, Tag &tg, const std::vector<Meas> &all, c
         return KFO_ST_FEW_RANGES;
     }
     if (!ml_estimate(all, seed, est, &it)) return KFO_ST_UPDATE_SKIPPED;
+    int itRank = 0; /* Gauss-Newton passes of the ranking solve, reported in the gain-iteration byte */
     if (pr.topN > 0) {
+        itRank = (int)all.size() > 4 ? it : 0; /* with exactly 4 ranges nothing is ranked away (the re-solve on the
+                                                  re-ordered ranges below still runs, as in the reference) */
         std::vector<double> d = distances(est, all);
         std::vector<std::pair<double, int>> q(all.size());
         for (size_t i = 0; i < all.size(); ++i) q[i] = {(d[i] - all[i].ranging) * (d[i] - all[i].ranging), (int)i};
@@ -730,7 +733,7 @@ unsigned ml_estimator(const Params &pr, Tag &tg, const std::vector<Meas> &all, c
     }
     tg.pos[0] = est.x; tg.pos[1] = est.y; tg.pos[2] = est.z;
     for (int k = 0; k < 9; ++k) tg.P[k] = est.cov.a[k];
-    return pack_status(0, 0, it, -1);
+    return pack_status(0, itRank, it, -1);
 }
 
 /* KalmanFilterTOAIMU::estimatePositionKF, KalmanFilterTOAIMU.cpp:100-195 */

@@ -1,18 +1,48 @@
-"""Second, independent restatement of the reference filters on numpy.linalg (LAPACK).
+"""Second, independent restatement of the reference filters, on the LAPACK drivers Armadillo itself calls.
 
-TEST INFRASTRUCTURE ONLY. PARITY UNPINNED (see kfpos_oracle.h). Its job is to cross-check
-the C++ oracle: same algorithm, different author-time, and LAPACK's inv/pinv/solve in place
-of the hand-written LU / Jacobi-SVD, which is also what Armadillo delegates to. One tag per
-object, pure-Python loops: small cases only.
+TEST INFRASTRUCTURE ONLY. PARITY UNPINNED (see kfpos_oracle.h). Its job is to cross-check the C++ oracle: same
+algorithm, different author-time, and -- instead of the C++ oracle's hand-written LU / Jacobi-SVD -- the LAPACK routines
+behind arma::inv / pinv / solve, reached through scipy.linalg.lapack (the same reference LAPACK interface; the BLAS
+underneath is whatever scipy ships, as it would be whatever the reference's host ships). One tag per object,
+pure-Python loops: small cases only.
+
+Which driver Armadillo calls depends on its version, and the reference pins none (CMakeLists.txt:29,
+find_package(Armadillo REQUIRED)). FLAVOUR selects one of three generations of the dispatch, so that the tests can
+state the spread over all of them instead of picking one (KFPOS_ARMA_FLAVOUR in the environment, or set_flavour()):
+
+  "lapack" (default) -- the general dense path every version ends in:
+      inv(A)                         dgetrf + dgetri                     (auxlib::inv)
+      pinv(A)                        dgesdd, cut at max(m,n) s_max eps   (op_pinv via svd_econ "dc")
+      solve(A, b, equilibrate)       dgesvx fact='E'; rcond < eps or failure -> dgelsd minimum-norm solution
+                                     (auxlib::solve_square_refine / solve_approx_svd)
+      solve(A, b)                    dgetrf + dgetrs + dgecon, same fallback (auxlib::solve_square_rcond)
+  "old"    -- Armadillo <= 8 as shipped with the ROS releases of the reference's time: as "lapack", but inv() of
+      matrices up to 4x4 in closed form (cofactors / determinant; the tiny-matrix path -- its exact expression order
+      is not restated, only its kind) and plain solve() through dgesv without a condition estimate
+  "new"    -- Armadillo >= 9/10: structure detection in front of the general path: inv() of a diagonal matrix by
+      reciprocals, of a matrix that looks symmetric positive definite by dpotrf + dpotri; pinv() of a symmetric matrix
+      through dsyevd; solve(.., equilibrate) of a matrix that looks sympd by dposvx fact='E'
 
 Reference map: MLLocation.cpp:24-37,153-278; KalmanFilterTOA.cpp:70-156,185-338,362-391,438-473;
 KalmanFilterTOAIMU.cpp:100-195,242-340,392-473 (with the 3-token repair of SURVEY.md 0.2).
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
+from scipy.linalg import lapack as _la
 
 EPS = np.finfo(np.float64).eps
+FLAVOURS = ("lapack", "old", "new")
+FLAVOUR = os.environ.get("KFPOS_ARMA_FLAVOUR", "lapack")
+
+
+def set_flavour(name: str):
+    global FLAVOUR
+    if name not in FLAVOURS:
+        raise ValueError(name)
+    FLAVOUR = name
 
 
 class LinAlgThrow(Exception):
@@ -23,37 +53,145 @@ def _stdmax(a, b):
     return b if a < b else a
 
 
+def _fortran(A):
+    return np.asfortranarray(A, dtype=np.float64)
+
+
+def _looks_sympd(A):
+    """Armadillo's cheap guess (sympd_helper::guess_sympd in kind): symmetric to a relative tolerance, positive
+    diagonal, no off-diagonal entry dominating the diagonal."""
+    n = A.shape[0]
+    if n < 2 or A.shape[0] != A.shape[1]:
+        return False
+    d = np.diag(A)
+    if np.any(d <= 0):
+        return False
+    tol = 100 * EPS
+    if np.any(np.abs(A - A.T) > tol * np.maximum(np.abs(A), np.abs(A.T)) + 0 * tol):
+        return False
+    off = np.abs(A - np.diag(d))
+    return bool(np.all(off.max(initial=0.0) < d.max())) and bool(np.all(2 * off <= d[:, None] + d[None, :]))
+
+
+def _inv_cofactor(A):
+    """closed-form inverse of a 1x1 .. 4x4 matrix: adjugate / determinant (FLAVOUR "old": the tiny-matrix path)"""
+    n = A.shape[0]
+    if n == 1:
+        if A[0, 0] == 0:
+            raise LinAlgThrow("inv")
+        return np.array([[1.0 / A[0, 0]]])
+    adj = np.empty((n, n))
+    for i in range(n):
+        for j in range(n):
+            minor = np.delete(np.delete(A, i, 0), j, 1)
+            adj[j, i] = (-1.0) ** (i + j) * _det_small(minor)
+    det = sum(A[0, j] * adj[j, 0] for j in range(n))
+    if not abs(det) >= EPS:   # the tiny path hands anything this small (or NaN) to LAPACK instead
+        return None
+    return adj / det
+
+
+def _det_small(M):
+    n = M.shape[0]
+    if n == 1:
+        return M[0, 0]
+    if n == 2:
+        return M[0, 0] * M[1, 1] - M[0, 1] * M[1, 0]
+    return sum((-1.0) ** j * M[0, j] * _det_small(np.delete(np.delete(M, 0, 0), j, 1)) for j in range(n))
+
+
 def arma_inv(A):
+    """arma::inv(A) for a square dense A. Throws (LinAlgThrow) where Armadillo's inv() returns false: an exactly
+    zero pivot."""
     if A.size == 0:
         return A.copy()
     if not np.all(np.isfinite(A)):
-        return np.full_like(A, np.nan)  # NaN in, NaN out (LAPACK getrf/getri do not reject it)
-    try:
-        return np.linalg.inv(A)
-    except np.linalg.LinAlgError as e:
-        raise LinAlgThrow("inv") from e
+        return np.full_like(A, np.nan)  # NaN in, NaN out (dgetrf / dgetri do not reject it)
+    n = A.shape[0]
+    if FLAVOUR == "old" and n <= 4:
+        out = _inv_cofactor(A)
+        if out is not None:
+            return out
+    if FLAVOUR == "new":
+        if n > 1 and not np.any(A - np.diag(np.diag(A))):  # is_diagmat(): reciprocals of the diagonal
+            d = np.diag(A)
+            if np.any(d == 0):
+                raise LinAlgThrow("inv")
+            return np.diag(1.0 / d)
+        if _looks_sympd(A):
+            c, info = _la.dpotrf(_fortran(A), lower=1)
+            if info == 0:
+                ci, info = _la.dpotri(c, lower=1)
+                if info == 0:
+                    low = np.tril(ci)
+                    return low + np.tril(ci, -1).T
+            # not positive definite after all: the general path
+    lu, piv, info = _la.dgetrf(_fortran(A))
+    if info != 0:
+        raise LinAlgThrow("inv")
+    out, info = _la.dgetri(lu, piv)
+    if info != 0:
+        raise LinAlgThrow("inv")
+    return np.ascontiguousarray(out)
 
 
 def arma_pinv(A):
+    """arma::pinv(A): SVD by divide and conquer, singular values <= max(m,n) s_max eps dropped."""
     if A.size == 0:
         return A.copy()
     if not np.all(np.isfinite(A)):
         raise LinAlgThrow("pinv")
-    U, s, Vt = np.linalg.svd(A)
+    if FLAVOUR == "new" and A.shape[0] == A.shape[1] and np.array_equal(A, A.T):
+        w, v, info = _la.dsyevd(_fortran(A), compute_v=1, lower=1)   # op_pinv::apply_sym
+        if info != 0:
+            raise LinAlgThrow("pinv")
+        aw = np.abs(w)
+        tol = A.shape[0] * aw.max() * EPS
+        keep = aw > tol
+        if not keep.any():
+            return np.zeros_like(A)
+        return (v[:, keep] / w[keep]) @ v[:, keep].T
+    u, s, vt, info = _la.dgesdd(_fortran(A), compute_uv=1, full_matrices=0)
+    if info != 0:
+        raise LinAlgThrow("pinv")
     tol = max(A.shape) * s[0] * EPS
     keep = s > tol
-    return (Vt[keep].T / s[keep]) @ U[:, keep].T
+    if not keep.any():
+        return np.zeros((A.shape[1], A.shape[0]))
+    return (vt[keep].T / s[keep]) @ u[:, keep].T
+
+
+def _approx_svd(A, b):
+    """auxlib::solve_approx_svd: the minimum-norm least-squares solution by dgelsd at machine-precision rank cut"""
+    m, n = A.shape
+    nrhs = 1
+    work, iwork, info = _la.dgelsd_lwork(m, n, nrhs, -1.0)
+    x, _, _, info = _la.dgelsd(_fortran(A), _fortran(b.reshape(-1, 1)), int(work), int(iwork), cond=-1.0)
+    if info != 0:
+        raise LinAlgThrow("solve")
+    return np.ascontiguousarray(x[:n, 0])
 
 
 def arma_solve_equilibrate(A, b):
+    """arma::solve(A, b, solve_opts::equilibrate), square A (MLLocation.cpp:210): the expert driver with
+    equilibration and iterative refinement; a singular or (rcond < eps) near-singular system gets the approximate
+    solution instead (Armadillo warns and carries on)."""
     if not (np.all(np.isfinite(A)) and np.all(np.isfinite(b))):
         return np.full_like(b, np.nan)  # the reference tests the result for NaN (KalmanFilterTOA.cpp:270)
-    if np.linalg.cond(A, 1) * EPS > 1.0:
-        return arma_pinv(A) @ b
-    try:
-        return np.linalg.solve(A, b)
-    except np.linalg.LinAlgError:
-        return arma_pinv(A) @ b
+    n = A.shape[0]
+    if FLAVOUR == "new" and _looks_sympd(A):
+        out = _la.dposvx(_fortran(A), _fortran(b.reshape(-1, 1)), fact="E", lower=1)
+        x, rcond, info = out[5], out[6], out[-1]   # a_s, lu, equed, s, b_s, x, rcond, ferr, berr, info
+        if (info == 0 or info == n + 1) and rcond >= EPS:
+            return np.ascontiguousarray(x[:, 0])
+        if info == 0 or info == n + 1:
+            return _approx_svd(A, b)
+        # not positive definite: the general expert driver
+    out = _la.dgesvx(_fortran(A), _fortran(b.reshape(-1, 1)), fact="E")
+    x, rcond, info = out[7], out[8], out[-1]
+    if (info == 0 or info == n + 1) and rcond >= EPS:
+        return np.ascontiguousarray(x[:, 0])
+    return _approx_svd(A, b)
 
 
 def distances(p, meas):
@@ -265,15 +403,23 @@ class NumpyFilter:
 # MLLocation::estimatePosition2D, MLLocation.cpp:48-143 (with the tentative-z repair of DESIGN.md).
 # ---------------------------------------------------------------------------------------------------
 def arma_solve(A, b):
-    """arma::solve(A, b) with default options: LU, and an approximate (SVD) solution when rcond is tiny."""
+    """arma::solve(A, b) with default options, square A (MLLocation.cpp:101): LU with a reciprocal condition
+    estimate, and the approximate (dgelsd) solution when rcond < eps; FLAVOUR "old": dgesv, approximate solution only
+    when the factorisation hits an exactly zero pivot."""
     if not (np.all(np.isfinite(A)) and np.all(np.isfinite(b))):
         return np.full_like(b, np.nan)
-    try:
-        if np.linalg.cond(A, 1) * EPS > 1.0:
-            return arma_pinv(A) @ b
-        return np.linalg.solve(A, b)
-    except np.linalg.LinAlgError:
-        return arma_pinv(A) @ b
+    if FLAVOUR == "old":
+        _, _, x, info = _la.dgesv(_fortran(A), _fortran(b.reshape(-1, 1)))
+        return np.ascontiguousarray(x[:, 0]) if info == 0 else _approx_svd(A, b)
+    anorm = _la.dlange("1", _fortran(A))
+    lu, piv, info = _la.dgetrf(_fortran(A))
+    if info != 0:
+        return _approx_svd(A, b)
+    rcond, info2 = _la.dgecon(lu, anorm, norm="1")
+    if info2 != 0 or rcond < EPS:
+        return _approx_svd(A, b)
+    x, info = _la.dgetrs(lu, piv, _fortran(b.reshape(-1, 1)))
+    return np.ascontiguousarray(x[:, 0])
 
 
 def ml_estimate_2d(meas, seed):

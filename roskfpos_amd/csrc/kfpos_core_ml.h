@@ -224,16 +224,18 @@ KFPOS_FN void set_weights_iekf(SC &sc, const Params &pr, double e_ml, uint64_t d
  *    weights_kept says that the weights of the kept set are already in place (set_weights_ml(sc, pr, drop) done). */
 template <bool SHARE, class SC>
 KFPOS_FN uint64_t topn_mask(const double seed[3], SC &sc, const Params &pr, int n_valid, MlFirst &first_all,
-                            bool &first_valid, bool &weights_kept) {
+                            bool &first_valid, bool &weights_kept, int *rank_iters = nullptr) {
     weights_kept = false;
     first_valid = false;
+    if (rank_iters) *rank_iters = 0;
     int ndrop = n_valid - 4 < pr.top_n ? n_valid - 4 : pr.top_n;
     if (ndrop <= 0) return 0;
     first_valid = SHARE; /* n_valid >= 5 here: the solve below does sweep */
     double p[3] = {seed[0], seed[1], seed[2]}, sse;
     set_weights_ml(sc, pr, 0ull);
     MlFirst unused = {};
-    ml_estimate(p, sc, pr, 0, n_valid, sse, false, unused, SHARE, first_all);
+    const int it_rank = ml_estimate(p, sc, pr, 0, n_valid, sse, false, unused, SHARE, first_all);
+    if (rank_iters) *rank_iters = it_rank;
     uint64_t drop = 0;
     if (SHARE && ndrop <= 2) {
         double v1 = -1.0, v2 = -1.0; /* largest, second largest residual^2; an absent range (-1) never gets in */
@@ -287,10 +289,10 @@ KFPOS_FN uint64_t topn_mask(const double seed[3], SC &sc, const Params &pr, int 
     return drop;
 }
 template <class SC>
-KFPOS_FN uint64_t topn_mask(const double seed[3], SC &sc, const Params &pr, int n_valid) {
+KFPOS_FN uint64_t topn_mask(const double seed[3], SC &sc, const Params &pr, int n_valid, int *rank_iters = nullptr) {
     MlFirst unused = {};
     bool valid, kept;
-    return topn_mask<false>(seed, sc, pr, n_valid, unused, valid, kept);
+    return topn_mask<false>(seed, sc, pr, n_valid, unused, valid, kept, rank_iters);
 }
 
 /* ================================================================== standalone ML estimator (ALGORITHM_ML) */
@@ -308,8 +310,9 @@ KFPOS_FN uint32_t step_ml(double pos[3], double cov[6], SC &sc, const Params &pr
         return ST_FEW_RANGES;
     }
     uint64_t drop = 0;
+    int it_rank = 0; /* Gauss-Newton passes of the ranking solve: reported in the status word's gain-iteration byte */
     if (pr.top_n > 0) {
-        drop = topn_mask(seed, sc, pr, n_valid); /* first solve + ranking */
+        drop = topn_mask(seed, sc, pr, n_valid, &it_rank); /* first solve + ranking */
         /* the first solve throws exactly when a used errorEstimation is 0 (its sse is NaN then) */
         if (ml_covariance_throws(sc, pr, 0, n_valid, NAN)) return ST_UPDATE_SKIPPED;
         n_valid = count_used(sc, pr, drop);
@@ -343,7 +346,7 @@ KFPOS_FN uint32_t step_ml(double pos[3], double cov[6], SC &sc, const Params &pr
     for (int k = 0; k < 3; ++k) pos[k] = p[k];
     KFPOS_UNROLL
     for (int k = 0; k < 6; ++k) cov[k] = c[k];
-    return pack_status(0, 0, it, -1);
+    return pack_status(0, it_rank, it, -1);
 }
 
 } // namespace kfpos

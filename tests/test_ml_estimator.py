@@ -22,71 +22,96 @@ def test_oracle_ml_estimator_ignore_n_beats_normal_with_outliers():
     assert err[1] < 0.5 * err[0]
 
 
+def _trace_epoch(w, s):
+    r = w.ranges_mm(s)
+    r[::5, 2] += 700
+    if s % 4 == 1:
+        r[:, 1] = -1
+    if s % 5 == 3:
+        r[::7, 3:] = 0      # fewer than 4 ranges: the seed comes back, no covariance
+    return r
+
+
+def _judge_epoch(sk, so, pk, po, ck, co, f32_inputs=False):
+    """One epoch of the standalone estimator, kernel (GPU or host build of the kernel body) against the oracle.
+
+    The Gauss-Newton loop stops on a relative cost change of 1e-3 (MLLocation.cpp:168) and has no damping: a solve
+    that needs many passes is wandering, and every pass multiplies whatever rounding difference two implementations
+    have. The status word carries the pass counts of both solves of an epoch -- the ranking solve of IGNORE_N in the
+    gain-iteration byte, the final solve in the ML byte -- so the comparison can say which regime a tag is in:
+      <= 15 passes (99 % of the tags from a good seed, 90 % from the default seed {1,1,4}): identical pass counts for
+                   EVERY tag, NORMAL and IGNORE_N alike, positions within 1e-9 m, covariances to 1e-5 relative;
+      16 .. 30   : identical pass counts still (measured: no flip below 35 passes in 250 000 tag-epochs), positions
+                   within 1e-3 m (measured: <= 1.4e-4 m; one Gauss-Newton pass near the stop threshold moves ~1e-4 m);
+      > 30       : a chaotic walk through the interior anchors; two correct implementations end metres apart and
+                   take different pass counts. Only finiteness is compared. Returns the number of such tags."""
+    assert np.array_equal(sk & 0xFF, so & 0xFF)                       # flags: few ranges, skipped, ...
+    passes = np.maximum((so >> 16) & 0xFF, (so >> 8) & 0xFF).astype(int)
+    few = (so & 4) != 0
+    tame, middle, wild = passes <= 15, (passes > 15) & (passes <= 30), passes > 30
+    same = (sk >> 8) == (so >> 8)
+    assert same[tame | middle].all(), np.flatnonzero(~same & (tame | middle))
+    d = np.abs(pk - po).max(1)
+    assert d[tame].max(initial=0.0) < (1e-7 if f32_inputs else 1e-9), d[tame].max()
+    assert d[middle].max(initial=0.0) < 1e-3
+    assert np.array_equal(np.isfinite(pk).all(1)[wild], np.isfinite(po).all(1)[wild])
+    ok = tame & ~few
+    assert np.allclose(ck[ok], co[ok], rtol=1e-5, atol=1e-14)
+    assert np.all(np.isnan(ck[few])) and np.all(np.isnan(co[few]))
+    return int(wild.sum())
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("A,top_n,seeded,storage", [(8, 0, True, 0), (8, 2, True, 0), (8, 1, False, 2),
-                                                     (16, 3, True, 0), (12, 2, True, 0)])
+                                                     (16, 3, True, 0), (12, 2, True, 0), (8, 0, False, 0),
+                                                     (16, 3, False, 0), (12, 2, False, 0)])
 def test_gpu_ml_estimator_matches_oracle(A, top_n, seeded, storage):
     from roskfpos_amd import capi
-    T, S = 200, 12
+    T, S = 2000, 12
     w = Workload(T, A)
     real = np.float32 if storage else np.float64
     seed = w.init_positions() + 0.25 if seeded else None
     gpu = capi.KfposBank(capi.MODEL_ML, T, w.anchors, storage=storage, top_n=top_n, init_pos=seed)
     orc = oracle_py.OracleBank(oracle_py.MODEL_ML, T, w.anchors, top_n=top_n, init_pos=seed, n_threads=8)
     err = w.err_est(real)
+    wild = 0
     for s in range(S):
-        r = w.ranges_mm(s)
-        r[::5, 2] += 700
-        if s % 4 == 1:
-            r[:, 1] = -1
-        if s % 5 == 3:
-            r[::7, 3:] = 0      # fewer than 4 ranges: the seed comes back, no covariance
+        r = _trace_epoch(w, s)
         sg = gpu.step_toa(r, err, 0.05)
         so = orc.step_toa(r, err.astype(np.float64), 0.05)
         pg, cg, _, _ = gpu.get_pose(0.0)
         po, co, _, _ = orc.get_pose(0.0)
-        assert np.array_equal(sg & 0xFF, so & 0xFF)
-        few = (so & 4) != 0
-        # The Gauss-Newton loop stops on a relative cost change of 1e-3 (MLLocation.cpp:168). IGNORE_N re-solves on
-        # the ranges in residual-sorted order, i.e. sums in another order than the kernel, so a stop decision
-        # that sits on the threshold can flip (one iteration more or fewer: ~1e-4 m when only 4 nearly coplanar
-        # anchors are left). Tags with the same iteration count must agree closely; flips must stay rare.
-        same_iters = ((sg >> 16) & 0xFF) == ((so >> 16) & 0xFF)
-        assert same_iters.mean() > 0.98
-        d = (pg - po)[same_iters]
-        assert np.sqrt((d ** 2).sum(1).mean()) < 1e-7 and np.abs(d).max() < 1e-6
-        assert np.median(np.abs(d).max(1)) < 1e-12
-        ok = same_iters & ~few
-        assert np.allclose(cg[ok], co[ok], rtol=1e-5, atol=1e-14)
-        assert np.all(np.isnan(cg[few])) and np.all(np.isnan(co[few]))
+        wild += _judge_epoch(sg, so, pg, po, cg, co)
+    if seeded:                      # from a seed 0.25 m off the truth hardly any solve wanders
+        assert wild <= 2e-4 * T * S, wild
     x, P, _ = gpu.get_state()
     assert x.shape == (T, 3) and P.shape == (T, 3, 3)
 
 
-@pytest.mark.parametrize("A,top_n,static", [(8, 0, False), (8, 2, True), (12, 2, False)])
-def test_kernel_math_ml_estimator_matches_oracle_on_cpu(A, top_n, static):
+@pytest.mark.parametrize("A,top_n,static,seeded", [(8, 0, False, True), (8, 2, True, True), (12, 2, False, True),
+                                                    (8, 0, True, False), (8, 1, True, False), (16, 3, False, False),
+                                                    (12, 2, False, False)])
+def test_kernel_math_ml_estimator_matches_oracle_on_cpu(A, top_n, static, seeded):
     """step_ml of kfpos_core.h compiled for the host (tests/emu) against the oracle."""
     from impls import emu_lib
-    T, S = 64, 8
+    T, S = 1000, 12
     w = Workload(T, A)
-    seed = np.ascontiguousarray(w.init_positions() + 0.25)
+    seed = np.ascontiguousarray(w.init_positions() + 0.25) if seeded else None
     L = emu_lib()
-    h = L.kfe_create(2, T, A, np.ascontiguousarray(w.anchors), 0.5, 0.5, 0, 0.5, top_n, 1, seed.ctypes.data)
+    h = L.kfe_create(2, T, A, np.ascontiguousarray(w.anchors), 0.5, 0.5, 0, 0.5, top_n, int(seeded),
+                     seed.ctypes.data if seeded else None)
     L.kfe_set_static(h, int(static))
-    orc = oracle_py.OracleBank(oracle_py.MODEL_ML, T, w.anchors, top_n=top_n, init_pos=seed)
+    orc = oracle_py.OracleBank(oracle_py.MODEL_ML, T, w.anchors, top_n=top_n, init_pos=seed, n_threads=8)
+    wild = 0
     for s in range(S):
-        r = w.ranges_mm(s)
-        r[::5, 2] += 700
-        if s % 4 == 1:
-            r[:, 1] = -1
+        r = _trace_epoch(w, s)
         se = np.zeros(T, dtype=np.uint32)
         L.kfe_step_toa(h, r, w.err_est(), np.array([0.05]), 1, se.ctypes.data)
         so = orc.step_toa(r, w.err_est(), 0.05)
         x, P = np.zeros((T, 3)), np.zeros((T, 3, 3))
         L.kfe_get_state(h, x, P)
         po, co, _, _ = orc.get_pose(0.0)
-        assert np.array_equal(se & 0xFF, so & 0xFF)
-        same = ((se >> 16) & 0xFF) == ((so >> 16) & 0xFF)
-        assert same.mean() > 0.98
-        assert np.abs(x - po)[same].max() < 1e-9 and np.allclose(P[same], co[same], rtol=1e-6, atol=1e-14)
+        wild += _judge_epoch(se, so, x, po, P, co)
+    if seeded:
+        assert wild <= 2e-4 * T * S, wild
     L.kfe_destroy(h)
