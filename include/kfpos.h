@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define KFPOS_VERSION 100 /* 0.1.0 */
+#define KFPOS_VERSION 101 /* 0.1.1: kfpos_config.ml_variant, kfpos_comm_* */
 
 /* ---- return codes (every entry point returns one; 0 = success) ---- */
 #define KFPOS_OK            0
@@ -40,8 +40,9 @@ extern "C" {
 #define KFPOS_MODEL_TOA     0 /* ALGORITHM_KF_TOA     -> KalmanFilterTOA, 6 states p,v */
 #define KFPOS_MODEL_TOA_IMU 1 /* ALGORITHM_KF_TOA_IMU -> KalmanFilterTOAIMU, 9 states p,v,a (3-token repair) */
 #define KFPOS_MODEL_ML      2 /* ALGORITHM_ML -> MLLocation as the estimator (MLLocation.cpp:421-486): 3-D, variant NORMAL
-                               (top_n = 0) or IGNORE_N (top_n = numRangingsToIgnore); state = position, P = its 3x3
-                               covariance; dt is ignored, use_init_pos selects the solver's seed ({1,1,4} otherwise) */
+                               (top_n = 0), IGNORE_N (top_n = numRangingsToIgnore) or BEST (kfpos_config.ml_variant);
+                               state = position, P = its 3x3 covariance; dt is ignored, use_init_pos selects the
+                               solver's seed ({1,1,4} otherwise) */
 #define KFPOS_MODEL_PLANAR  3 /* ALGORITHM_KF -> KalmanFilter (KalmanFilter.cpp): 8 states [x y vx vy ax ay theta omega] at a
                                fixed height, fed by ranging epochs and, optionally, PX4Flow / IMU / magnetometer /
                                compass samples (kfpos_step_sensor). Configure with kfpos_set_planar() before stepping */
@@ -92,7 +93,17 @@ typedef struct kfpos_config {
     double  init_pos[3];    /* initialPosition for every tag                   [initPositionX/Y/Z]; per-tag values:
                                kfpos_set_init_positions() */
     int32_t device;         /* HIP device ordinal */
+    int32_t ml_variant;     /* KFPOS_MODEL_ML only (0 otherwise): KFPOS_ML_NORMAL / _IGNORE_N / _BEST  [variant],
+                               MLLocation.h:5-7, Posgenerator.cpp:79-83 */
 } kfpos_config;
+#define KFPOS_ML_NORMAL   0 /* estimatePosition (MLLocation.cpp:153-257); with top_n > 0 it acts as IGNORE_N */
+#define KFPOS_ML_IGNORE_N 1 /* estimatePositionIgnoreN (:307-347) with numRangingsToIgnore = top_n */
+#define KFPOS_ML_BEST     2 /* estimatePositionBestGroup (:348-414): every subset of 4 ranges, smallest covariance trace
+                               wins. Defined by the reference for 4 or 5 ranges only -- its erase loop (:377-381) runs past
+                               the end of the vector from 6 ranges on -- so kfpos_set_anchors refuses more than 5 anchors
+                               for this variant (KFPOS_ERR_MODEL); top_n is ignored, as numRangingsToIgnore is there.
+                               Status word: KFPOS_ST_IGNORED = the range the winning group did without, KFPOS_ST_GAIN_ITERS
+                               = the most Gauss-Newton passes any group took */
 
 /* KFPOS_MODEL_PLANAR only: the attributes KalmanFilter::loadConfigurationFiles reads from the four XML
  * parameters (KalmanFilter.cpp:748-842; config_uwb.xml / config_px4flow.xml / config_imu.xml / config_mag.xml

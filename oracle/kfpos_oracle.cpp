@@ -444,6 +444,7 @@ struct Tag {
 
 struct Params {
     int model, n, topN;
+    int mlVariant = 0; /* ALGORITHM_ML: ML_VARIANT_NORMAL 0 / IGNORE_N 1 / BEST 2 (MLLocation.h:5-7) */
     double accelNoise, jolt, costThreshold;
     bool ignoreWorst, useFixedInit;
     /* 8-state planar filter (KalmanFilter): <uwb useFixedHeight fixedHeight/> of config_uwb.xml, initAngle */
@@ -703,9 +704,14 @@ unsigned toa6_estimate(const Params &pr, Tag &tg, const std::vector<Meas> &allIn
  * getPose solves it from the never-updated _previousEstimation (:421-469): variant NORMAL 3-D
  * (estimatePosition) or IGNORE_N (estimatePositionIgnoreN, :307-347, which re-solves on the ranges SORTED by
  * residual minus the worst min(n-4, N)). The solve is deterministic, so it is done here once per epoch and
- * kept in the tag: pos = estimate, P (3x3) = its covariance. The 2-D and BestGroup variants are not restated:
- * getPose indexes (0,2) of the 2x2 covariance of estimatePosition2D, and estimatePositionBestGroup erases
- * through shifting indices (:379-383), both undefined beyond trivial sizes. */
+ * kept in the tag: pos = estimate, P (3x3) = its covariance. The 2-D variant is not restated: getPose indexes (0,2)
+ * of the 2x2 covariance of estimatePosition2D. BEST (estimatePositionBestGroup, :348-414) is restated where the
+ * reference defines it -- 4 or 5 ranges: its erase loop (:377-381) removes by an index into the vector it is shrinking,
+ * so with two or more ranges to drop (6 ranges and more) the second erase hits end() or beyond -- undefined behaviour
+ * from the very first group (v = 1111 0..0 ends in a false at index n-1). With 4 ranges there is one group (all of
+ * them), with 5 there are five, each missing exactly one range, in std::prev_permutation order: without range 4, 3, 2,
+ * 1, 0. The group with the smallest trace of its covariance wins; `<=` (:407) lets a later group win a tie, and a NaN
+ * trace never wins unless it is the first. */
 unsigned ml_estimator(const Params &pr, Tag &tg, const std::vector<Meas> &all, const double seed3[3]) {
     tg.started = true;
     Pos3 seed{seed3[0], seed3[1], seed3[2], Mat()}, est;
@@ -715,7 +721,46 @@ unsigned ml_estimator(const Params &pr, Tag &tg, const std::vector<Meas> &all, c
         for (int k = 0; k < 9; ++k) tg.P[k] = NAN;
         return KFO_ST_FEW_RANGES;
     }
-    if (!ml_estimate(all, seed, est, &it)) return KFO_ST_UPDATE_SKIPPED;
+    if (!ml_estimate(all, seed, est, &it)) return KFO_ST_UPDATE_SKIPPED; /* (BEST: :357-366, then thrown away) */
+    if (pr.mlVariant == 2) {
+        const int n = (int)all.size();
+        if (n > 5) return KFO_ST_UPDATE_SKIPPED; /* undefined in the reference (erase(end()), :379-381) */
+        std::vector<Pos3> groups;
+        std::vector<int> left_out, passes;
+        std::vector<bool> v(n);
+        std::fill(v.begin(), v.begin() + 4, true);
+        do {
+            std::vector<Meas> nr(all);
+            int out = -1;
+            for (int i = 0; i < n; ++i) {
+                if (!v[i]) {
+                    nr.erase(nr.begin() + i); /* at most one erase for n <= 5: the index is still the original one */
+                    out = i;
+                }
+            }
+            Pos3 g;
+            int git = 0;
+            if (!ml_estimate(nr, seed, g, &git)) return KFO_ST_UPDATE_SKIPPED; /* inv() throws out of getPose */
+            groups.push_back(g);
+            left_out.push_back(out);
+            passes.push_back(git);
+        } while (std::prev_permutation(v.begin(), v.end()));
+        double minError = 0;
+        int minIndex = -1;
+        for (int i = 0; i < (int)groups.size(); ++i) { /* :398-411 */
+            const double currentError = groups[i].cov(0, 0) + groups[i].cov(1, 1) + groups[i].cov(2, 2);
+            if (minIndex == -1) { minIndex = i; minError = currentError; }
+            if (currentError <= minError) { minIndex = i; minError = currentError; }
+        }
+        const Pos3 &b = groups[minIndex];
+        tg.pos[0] = b.x; tg.pos[1] = b.y; tg.pos[2] = b.z;
+        for (int k = 0; k < 9; ++k) tg.P[k] = b.cov.a[k];
+        int most = 0;
+        for (int q : passes) most = std::max(most, q);
+        /* gain-iteration byte: the most Gauss-Newton passes any group took; ML byte: the winner's; ignored: the range
+         * (index among this epoch's > 0 ranges) the winning group did without */
+        return pack_status(0, most, passes[minIndex], left_out[minIndex]);
+    }
     int itRank = 0; /* Gauss-Newton passes of the ranking solve, reported in the gain-iteration byte */
     if (pr.topN > 0) {
         itRank = (int)all.size() > 4 ? it : 0; /* with exactly 4 ranges nothing is ranked away (the re-solve on the
@@ -1087,6 +1132,8 @@ template <class Fn> void planar_each(kfo_filter_bank *o, const double *dt, int d
 } // namespace
 
 extern "C" {
+
+void kfo_set_ml_variant(kfo_filter_bank *o, int variant) { o->pr.mlVariant = variant; }
 
 kfo_filter_bank *kfo_create(int model, int n_tags, int max_anchors, double accel_noise, double jolt,
                             int ignore_worst, double cost_threshold, int top_n, int use_init_pos,

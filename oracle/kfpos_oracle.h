@@ -42,6 +42,8 @@ typedef struct kfo_filter_bank kfo_filter_bank;
  * 24..31: 1 + index (into the >0 ranges of the epoch) of the anchor dropped by
  * the leave-one-out heuristic, 0 if none. */
 
+/* ALGORITHM_ML: 0 NORMAL / 1 IGNORE_N (= top_n > 0) / 2 BEST (estimatePositionBestGroup; defined for 4 or 5 ranges) */
+void kfo_set_ml_variant(kfo_filter_bank *o, int variant);
 kfo_filter_bank *kfo_create(int model, int n_tags, int max_anchors,
                             double accel_noise, double jolt,
                             int ignore_worst, double cost_threshold, int top_n,

@@ -52,6 +52,7 @@ def lib():
         L.kfo_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_double,
                                  C.c_int, C.c_int, C.c_void_p]
         L.kfo_destroy.argtypes = [C.c_void_p]
+        L.kfo_set_ml_variant.argtypes = [C.c_void_p, C.c_int]
         L.kfo_state_dim.argtypes = [C.c_void_p]
         L.kfo_set_anchors.argtypes = [C.c_void_p, _dp, C.c_int]
         L.kfo_step_toa.argtypes = [C.c_void_p, _ip, _dp, _dp, C.c_int, C.c_void_p, C.c_int]
@@ -83,7 +84,7 @@ class OracleBank:
     """T independent reference filters (KalmanFilterTOA or repaired KalmanFilterTOAIMU)."""
 
     def __init__(self, model, n_tags, anchors, accel_noise=0.5, jolt=0.5, ignore_worst=False,
-                 cost_threshold=0.5, top_n=0, init_pos=None, n_threads=1, planar=None):
+                 cost_threshold=0.5, top_n=0, init_pos=None, n_threads=1, planar=None, ml_variant=0):
         self.model, self.T = model, n_tags
         self.anchors = _f64(anchors)
         self.A = self.anchors.shape[0]
@@ -96,6 +97,8 @@ class OracleBank:
                                    cost_threshold, top_n, int(init_pos is not None),
                                    ip.ctypes.data if ip is not None else None)
         lib().kfo_set_anchors(self._h, self.anchors, self.A)
+        if ml_variant:
+            lib().kfo_set_ml_variant(self._h, ml_variant)
         self.n = lib().kfo_state_dim(self._h)
         if model == MODEL_PLANAR:
             self.planar = PlanarConfig(**(planar or {}))

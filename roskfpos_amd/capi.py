@@ -19,6 +19,7 @@ MODEL_TOA, MODEL_TOA_IMU, MODEL_ML, MODEL_PLANAR = 0, 1, 2, 3
 SENSOR_PX4FLOW, SENSOR_IMU, SENSOR_MAG, SENSOR_COMPASS = 1, 2, 3, 4
 _SENSOR_WIDTH = {1: 5, 2: 24, 3: 3, 4: 1}
 STORE_F64, STORE_F32, STORE_MIXED = 0, 1, 2
+ML_NORMAL, ML_IGNORE_N, ML_BEST = 0, 1, 2
 MAX_ANCHORS = 64
 ST_UPDATE_SKIPPED, ST_ML_FALLBACK, ST_FEW_RANGES, ST_ML_INIT, ST_NOT_STARTED, ST_NONFINITE = 1, 2, 4, 8, 16, 32
 ST_SKIPPED = 64
@@ -52,7 +53,8 @@ class _Config(C.Structure):
     _fields_ = [("model", C.c_int32), ("n_tags", C.c_int32), ("max_anchors", C.c_int32),
                 ("storage", C.c_int32), ("accel_noise", C.c_double), ("jolt", C.c_double),
                 ("ignore_worst", C.c_int32), ("cost_threshold", C.c_double), ("top_n", C.c_int32),
-                ("use_init_pos", C.c_int32), ("init_pos", C.c_double * 3), ("device", C.c_int32)]
+                ("use_init_pos", C.c_int32), ("init_pos", C.c_double * 3), ("device", C.c_int32),
+                ("ml_variant", C.c_int32)]
 
 
 class PlanarConfig(C.Structure):
@@ -168,7 +170,7 @@ class KfposBank:
 
     def __init__(self, model, n_tags, anchors, storage=STORE_F64, accel_noise=0.5, jolt=0.5,
                  ignore_worst=False, cost_threshold=0.5, top_n=0, init_pos=None, device=0,
-                 max_anchors=None, planar=None):
+                 max_anchors=None, planar=None, ml_variant=0):
         self._h = None
         self.lib = load()
         anchors = np.ascontiguousarray(anchors, dtype=np.float64)
@@ -189,6 +191,7 @@ class KfposBank:
                 assert ip.shape == (self.T, 3)
                 per_tag = np.ascontiguousarray(ip)
         cfg.device = device
+        cfg.ml_variant = ml_variant  # MODEL_ML: ML_NORMAL / ML_IGNORE_N / ML_BEST
         h = C.c_void_p()
         self._chk(self.lib.kfpos_create(C.byref(cfg), C.byref(h)))
         self._h = h

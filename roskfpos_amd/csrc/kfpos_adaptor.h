@@ -7,7 +7,7 @@
  *   KalmanFilterTOA               src/kfpos/algorithms/KalmanFilterTOA.h:18-54
  *   KalmanFilterTOAIMU            src/kfpos/algorithms/KalmanFilterTOAIMU.h:16-78
  *   KalmanFilter                  src/kfpos/algorithms/KalmanFilter.h:29-133 (8-state planar filter, ALGORITHM_KF)
- *   MLLocation                    src/kfpos/algorithms/MLLocation.h:26-70 as an estimator (ALGORITHM_ML; 3-D, variants 0 and 1)
+ *   MLLocation                    src/kfpos/algorithms/MLLocation.h:26-70 as an estimator (ALGORITHM_ML; 3-D, variants 0, 1 and -- up to 5 beacons -- 2)
  *   Vector3 / VectorDim3 / Beacon src/kfpos/algorithms/sensor_types.h:7-25
  * Differences, all at the type level: Vector3::covarianceMatrix is a fixed-capacity matrix with the arma::mat
  * accessors the node uses (the reference embeds an arma::mat); the estimator reads time from an injectable clock
@@ -156,7 +156,10 @@ public:
 
 protected:
     SingleTagFilter(int model, double accelNoise, double jolt, bool ignoreWorst, double costThreshold,
-                    bool fixed, const Vector3 *init, int topN = 0) {
+                    bool fixed, const Vector3 *init, int topN = 0, int mlVariant = KFPOS_ML_NORMAL, bool use2d = false,
+                    int variantAsGiven = 0) {
+        if (use2d) throw std::invalid_argument("MLLocation: use2d has no defined result in the reference (getPose, MLLocation.cpp:456-464)");
+        if (variantAsGiven < 0 || variantAsGiven > 2) throw std::invalid_argument("MLLocation: variant is not one of ML_VARIANT_*");
         kfpos_config c;
         std::memset(&c, 0, sizeof(c));
         c.model = model;
@@ -168,6 +171,7 @@ protected:
         c.ignore_worst = ignoreWorst ? 1 : 0;
         c.cost_threshold = costThreshold;
         c.top_n = topN;
+        c.ml_variant = mlVariant;
         c.use_init_pos = fixed ? 1 : 0;
         if (init) { c.init_pos[0] = init->x; c.init_pos[1] = init->y; c.init_pos[2] = init->z; }
         check(kfpos_create(&c, &h_));
@@ -263,16 +267,14 @@ class MLLocation : public SingleTagFilter {
 public:
     /* _previousEstimation = {1,1,4} (MLLocation.cpp:3-12) */
     MLLocation() : SingleTagFilter(KFPOS_MODEL_ML, 0.0, 0.0, false, 0.0, false, nullptr) {}
-    /* MLLocation.cpp:14-22. Offered: the 3-D solver, variants NORMAL and IGNORE_N. The 2-D variant indexes (0,2) of a
-     * 2x2 covariance in getPose (:456-464) and BEST erases through shifting indices (:379-383): neither has a
-     * defined result in the reference, both are refused here. */
+    /* MLLocation.cpp:14-22. Offered: the 3-D solver, variants NORMAL, IGNORE_N and BEST. The 2-D variant indexes (0,2)
+     * of a 2x2 covariance in getPose (:456-464): no defined result in the reference, refused here. BEST is defined for 4
+     * or 5 ranges (its erase loop, :377-381, runs past the end of the vector from 6 on): newTOAMeasurement with more
+     * than 5 beacons throws std::runtime_error (kfpos_set_anchors: KFPOS_ERR_MODEL). */
     MLLocation(bool use2d, int variant, int numRangingsToIgnore, const Vector3 &previousEstimation)
         : SingleTagFilter(KFPOS_MODEL_ML, 0.0, 0.0, false, 0.0, true, &previousEstimation,
-                          variant == ML_VARIANT_IGNORE_N ? numRangingsToIgnore : 0) {
-        if (use2d) throw std::invalid_argument("MLLocation: use2d has no defined result in the reference (getPose, MLLocation.cpp:456-464)");
-        if (variant != ML_VARIANT_NORMAL && variant != ML_VARIANT_IGNORE_N)
-            throw std::invalid_argument("MLLocation: variant BEST has no defined result in the reference (MLLocation.cpp:379-383)");
-    }
+                          variant == ML_VARIANT_IGNORE_N ? numRangingsToIgnore : 0,
+                          variant == ML_VARIANT_BEST ? KFPOS_ML_BEST : KFPOS_ML_NORMAL, use2d, variant) {}
     /* getPose solves from the stored ranges and the fixed seed every time (:426-441): no extrapolation, no clock.
      * Before the first ranging epoch the reference indexes an empty covariance; here getPose returns false. */
     bool getPose(Vector3 &pose) override {

@@ -209,6 +209,7 @@ struct Params {
     int n_anchors;
     double accel_noise, jolt, cost_threshold;
     int ignore_worst, top_n, use_init_pos;
+    int ml_variant = 0; /* standalone ML estimator: 0 NORMAL / 1 IGNORE_N (acts through top_n) / 2 BEST (MLLocation.h:5-7) */
     /* 8-state planar filter only: what KalmanFilter::loadConfigurationFiles reads (KalmanFilter.cpp:748-842) */
     int use_fixed_height, imu_fixed_cov_acc, imu_fixed_cov_w;
     double px4_height, px4_arm_p1, px4_arm_p2, px4_cov_vel, px4_cov_gyro_z;

@@ -296,9 +296,55 @@ KFPOS_FN uint64_t topn_mask(const double seed[3], SC &sc, const Params &pr, int 
 }
 
 /* ================================================================== standalone ML estimator (ALGORITHM_ML) */
-/* MLLocation::newTOAMeasurement + getPose (MLLocation.cpp:421-486), variant NORMAL 3-D or IGNORE_N
- * (estimatePositionIgnoreN, :307-347): solve from the fixed seed (_previousEstimation is never updated),
- * optionally drop the min(n-4, N) largest residuals and solve again, return position + 3x3 covariance. */
+/* MLLocation::newTOAMeasurement + getPose (MLLocation.cpp:421-486): solve from the fixed seed (_previousEstimation is
+ * never updated), return position + 3x3 covariance. Variants (Params::ml_variant, MLLocation.h:5-7):
+ *   NORMAL 3-D   estimatePosition (:153-257)
+ *   IGNORE_N     estimatePositionIgnoreN (:307-347): drop the min(n-4, N) largest residuals and solve again
+ *   BEST         estimatePositionBestGroup (:348-414), where the reference defines it: 4 or 5 ranges (below) */
+constexpr int ML_VARIANT_BEST_GROUP = 2;
+
+/* one solve over the ranges not in `drop`, with its covariance (over those ranges only). false: the reference throws
+ * (an errorEstimation of exactly 0, or an exactly singular J' W J) */
+template <class SC>
+KFPOS_FN bool ml_solve_cov(const double seed[3], SC &sc, const Params &pr, uint64_t drop, int n_used, double p[3],
+                           double c[6], int &it) {
+    p[0] = seed[0]; p[1] = seed[1]; p[2] = seed[2];
+    double sse;
+    set_weights_ml(sc, pr, drop);
+    it = ml_estimate(p, sc, pr, drop, n_used, sse);
+    if (ml_covariance_throws(sc, pr, drop, n_used, sse)) return false;
+    double m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0, cf[6];
+    for_anchors<SC>(pr, [&](int a) {
+        const bool on = used(sc, a, drop);
+        const double dx = p[0] - pr.anchors[3 * a], dy = p[1] - pr.anchors[3 * a + 1],
+                     dz = p[2] - pr.anchors[3 * a + 2];
+        const double invd = 1.0 / sqrt(dx * dx + dy * dy + dz * dz);
+        const double w = on ? 1.0 / stdmax(sc.E(a), sse) : 0.0;
+        const double gx = dx * invd, gy = dy * invd, gz = dz * invd;
+        m0 += w * gx * gx; m1 += w * gx * gy; m2 += w * gx * gz;
+        m3 += w * gy * gy; m4 += w * gy * gz; m5 += w * gz * gz;
+    });
+    const double m[6] = {m0, m1, m2, m3, m4, m5};
+    const double det = sym3_cofactors(m, cf);
+    if (det == 0.0) return false; /* inv() of an exactly singular J' W J throws */
+    const double idet = 1.0 / det;
+    KFPOS_UNROLL
+    for (int k = 0; k < 6; ++k) c[k] = cf[k] * idet;
+    return true;
+}
+
+/* anchor index of the k-th (0-based) range of this epoch that is present */
+template <class SC>
+KFPOS_FN int nth_present(const SC &sc, const Params &pr, int k) {
+    int seen = 0, at = 0;
+    for_anchors<SC>(pr, [&](int a) {
+        const bool on = used(sc, a, 0ull);
+        at = (on && seen == k) ? a : at;
+        seen += on ? 1 : 0;
+    });
+    return at;
+}
+
 template <class SC>
 KFPOS_FN uint32_t step_ml(double pos[3], double cov[6], SC &sc, const Params &pr, const double seed[3]) {
     int n_valid = count_used(sc, pr, 0);
@@ -309,6 +355,49 @@ KFPOS_FN uint32_t step_ml(double pos[3], double cov[6], SC &sc, const Params &pr
         for (int k = 0; k < 6; ++k) cov[k] = NAN;
         return ST_FEW_RANGES;
     }
+    double p[3], c[6];
+    int it = 0;
+    if (pr.ml_variant == ML_VARIANT_BEST_GROUP) {
+        /* estimatePositionBestGroup enumerates the subsets of 4 ranges with std::prev_permutation over a mask and
+         * removes the unselected ranges with erase(begin() + i) on the vector it is shrinking (:377-381): with two or
+         * more ranges to remove the second erase addresses end() or beyond -- undefined from the first group on, so 6
+         * ranges and more have no result to restate (kfpos_set_anchors refuses such a table for this variant). With 4
+         * ranges there is one group, all of them; with 5 there are five, each without exactly one range, in the order
+         * "without range 4, 3, 2, 1, 0" (indices among the ranges present). The smallest covariance trace wins, a
+         * later group wins a tie (`<=`, :407), a NaN trace only if it is the first group's. */
+        if (n_valid > 5) return ST_UPDATE_SKIPPED;
+        /* the solve over ALL ranges the reference runs first and throws away (:357-366) still throws when an
+         * errorEstimation is 0 */
+        if (ml_covariance_throws(sc, pr, 0, n_valid, NAN)) return ST_UPDATE_SKIPPED;
+        const int groups = n_valid == 4 ? 1 : 5;
+        double best_trace = 0.0;
+        int best_it = 0, best_out = -1, most = 0;
+        for (int g = 0; g < groups; ++g) {
+            const int out = n_valid == 4 ? -1 : 4 - g;
+            const uint64_t drop = out < 0 ? 0ull : (1ull << nth_present(sc, pr, out));
+            double gp[3], gc[6];
+            int git;
+            if (!ml_solve_cov(seed, sc, pr, drop, 4, gp, gc, git)) return ST_UPDATE_SKIPPED;
+            const double trace = gc[0] + gc[3] + gc[5];
+            most = git > most ? git : most;
+            if (g == 0 || trace <= best_trace) {
+                best_trace = trace;
+                best_it = git;
+                best_out = out;
+                KFPOS_UNROLL
+                for (int k = 0; k < 3; ++k) p[k] = gp[k];
+                KFPOS_UNROLL
+                for (int k = 0; k < 6; ++k) c[k] = gc[k];
+            }
+        }
+        KFPOS_UNROLL
+        for (int k = 0; k < 3; ++k) pos[k] = p[k];
+        KFPOS_UNROLL
+        for (int k = 0; k < 6; ++k) cov[k] = c[k];
+        /* gain-iteration byte: the most Gauss-Newton passes any group took; ML byte: the winner's; ignored: the range
+         * the winning group did without (index among this epoch's ranges), -1 with four ranges */
+        return pack_status(0, most, best_it, best_out);
+    }
     uint64_t drop = 0;
     int it_rank = 0; /* Gauss-Newton passes of the ranking solve: reported in the status word's gain-iteration byte */
     if (pr.top_n > 0) {
@@ -317,31 +406,7 @@ KFPOS_FN uint32_t step_ml(double pos[3], double cov[6], SC &sc, const Params &pr
         if (ml_covariance_throws(sc, pr, 0, n_valid, NAN)) return ST_UPDATE_SKIPPED;
         n_valid = count_used(sc, pr, drop);
     }
-    double p[3] = {seed[0], seed[1], seed[2]}, sse;
-    set_weights_ml(sc, pr, drop);
-    const int it = ml_estimate(p, sc, pr, drop, n_valid, sse);
-    if (ml_covariance_throws(sc, pr, drop, n_valid, sse)) return ST_UPDATE_SKIPPED;
-    double c[6];
-    /* covariance over the kept ranges only */
-    {
-        double m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0, cf[6];
-        for_anchors<SC>(pr, [&](int a) {
-            const bool on = used(sc, a, drop);
-            const double dx = p[0] - pr.anchors[3 * a], dy = p[1] - pr.anchors[3 * a + 1],
-                         dz = p[2] - pr.anchors[3 * a + 2];
-            const double invd = 1.0 / sqrt(dx * dx + dy * dy + dz * dz);
-            const double w = on ? 1.0 / stdmax(sc.E(a), sse) : 0.0;
-            const double gx = dx * invd, gy = dy * invd, gz = dz * invd;
-            m0 += w * gx * gx; m1 += w * gx * gy; m2 += w * gx * gz;
-            m3 += w * gy * gy; m4 += w * gy * gz; m5 += w * gz * gz;
-        });
-        const double m[6] = {m0, m1, m2, m3, m4, m5};
-        const double det = sym3_cofactors(m, cf);
-        if (det == 0.0) return ST_UPDATE_SKIPPED; /* inv() of an exactly singular J' W J throws */
-        const double idet = 1.0 / det;
-        KFPOS_UNROLL
-        for (int k = 0; k < 6; ++k) c[k] = cf[k] * idet;
-    }
+    if (!ml_solve_cov(seed, sc, pr, drop, n_valid, p, c, it)) return ST_UPDATE_SKIPPED;
     KFPOS_UNROLL
     for (int k = 0; k < 3; ++k) pos[k] = p[k];
     KFPOS_UNROLL

@@ -75,7 +75,7 @@ struct KArgs {
     double anchors[KFPOS_MAX_ANCHORS * 3];
     int T, A;
     double accel_noise, jolt, cost_threshold;
-    int ignore_worst, top_n, use_init_pos;
+    int ignore_worst, top_n, use_init_pos, ml_variant;
     int pair9;        /* 9-state kernel: two lanes per tag for the tail of the gain iteration (KFPOS_PAIR9=1; off by default: DESIGN 6a) */
     /* planar filter configuration (kfpos_planar_config) */
     int use_fixed_height, imu_fixed_cov_acc, imu_fixed_cov_w;
@@ -130,6 +130,7 @@ __device__ inline P make_params_of(const KArgs &a) {
     pr.cost_threshold = a.cost_threshold;
     pr.ignore_worst = a.ignore_worst;
     pr.top_n = a.top_n;
+    pr.ml_variant = a.ml_variant;
     pr.use_init_pos = a.use_init_pos;
     pr.use_fixed_height = a.use_fixed_height;
     pr.imu_fixed_cov_acc = a.imu_fixed_cov_acc;
@@ -1033,6 +1034,7 @@ void fill_args(const kfpos_handle *h, KArgs &a) {
     a.cost_threshold = h->cfg.cost_threshold;
     a.ignore_worst = h->cfg.ignore_worst;
     a.top_n = h->cfg.top_n;
+    a.ml_variant = h->cfg.model == KFPOS_MODEL_ML ? h->cfg.ml_variant : 0;
     a.pair9 = h->pair9 ? 1 : 0;
     a.use_init_pos = h->cfg.use_init_pos;
     a.use_fixed_height = h->planar.use_fixed_height;
@@ -1361,6 +1363,10 @@ int kfpos_create(const kfpos_config *cfg, kfpos_handle **out) {
     if (cfg->max_anchors < 1 || cfg->max_anchors > KFPOS_MAX_ANCHORS)
         return bad("kfpos_config.max_anchors must be 1..64 (MAX_NUM_ANCS, Posgenerator.h:74)");
     if (cfg->top_n < 0) return bad("kfpos_config.top_n must be >= 0");
+    if (cfg->ml_variant != KFPOS_ML_NORMAL && cfg->ml_variant != KFPOS_ML_IGNORE_N && cfg->ml_variant != KFPOS_ML_BEST)
+        return bad("kfpos_config.ml_variant is not one of KFPOS_ML_*");
+    if (cfg->ml_variant != KFPOS_ML_NORMAL && cfg->model != KFPOS_MODEL_ML)
+        return bad("kfpos_config.ml_variant belongs to KFPOS_MODEL_ML (MLLocation's variants, MLLocation.h:5-7)");
     if ((cfg->model == KFPOS_MODEL_TOA_IMU && (cfg->top_n || cfg->ignore_worst)) ||
         (cfg->model == KFPOS_MODEL_ML && cfg->ignore_worst) ||
         (cfg->model == KFPOS_MODEL_PLANAR && (cfg->top_n || cfg->ignore_worst)))
@@ -1543,6 +1549,11 @@ int kfpos_set_anchors(kfpos_handle *h, const double *xyz, const int32_t *ids, in
     g_err.clear();
     (void)ids;
     if (!h || !xyz || n_anchors < 1 || n_anchors > h->cfg.max_anchors) return KFPOS_ERR_ARG;
+    if (h->cfg.model == KFPOS_MODEL_ML && h->cfg.ml_variant == KFPOS_ML_BEST && n_anchors > 5) {
+        g_err = "estimatePositionBestGroup has no defined result for more than 5 ranges: its erase loop removes by an index "
+                "into the vector it is shrinking and runs past the end from the first group on (MLLocation.cpp:377-381)";
+        return KFPOS_ERR_MODEL;
+    }
     std::memset(h->anchors, 0, sizeof(h->anchors));
     std::memcpy(h->anchors, xyz, sizeof(double) * 3 * n_anchors);
     h->A = n_anchors;

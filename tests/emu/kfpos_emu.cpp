@@ -120,6 +120,7 @@ kfe_bank *kfe_create(int model, int n_tags, int n_anchors, const double *anchors
 }
 void kfe_destroy(kfe_bank *b) { delete b; }
 void kfe_set_static(kfe_bank *b, int on) { b->use_static = on; }
+void kfe_set_ml_variant(kfe_bank *b, int variant) { b->pr.ml_variant = variant; } /* ALGORITHM_ML: 2 = BEST */
 /* cfg: the 14 fields of kfpos_planar_config in order, as doubles */
 void kfe_set_planar(kfe_bank *b, const double *cfg, int sensors) {
     Params &p = b->pr;

@@ -84,6 +84,7 @@ def emu_lib():
                                  C.c_int, C.c_int, C.c_void_p]
         L.kfe_destroy.argtypes = [C.c_void_p]
         L.kfe_set_static.argtypes = [C.c_void_p, C.c_int]
+        L.kfe_set_ml_variant.argtypes = [C.c_void_p, C.c_int]
         L.kfe_step_toa.argtypes = [C.c_void_p, ip, dp, dp, C.c_int, C.c_void_p]
         L.kfe_step_imu.argtypes = [C.c_void_p, dp, dp, dp, C.c_int, C.c_void_p]
         L.kfe_latch_imu.argtypes = [C.c_void_p, dp, dp]
