@@ -1,7 +1,7 @@
 /*
  * kfpos_core.h -- per-tag arithmetic of the batched EKF core (one filter per lane).
  *
- * This is the body every HIP kernel in kfpos_hip.hip runs for one tag. It is written against
+ * This is the body every HIP kernel in kfpos_k_*.hip runs for one tag. It is written against
  * plain doubles and compile-time-indexed arrays only (everything unrolls into registers; the
  * only device builtins are the v_rcp_f64 / v_rsq_f64 seeds in kf_rcp / kf_rsqrt), so the same
  * text also compiles with g++ into the host emulation used by the CPU tests (tests/emu) to

@@ -1,35 +1,8 @@
 /*
- * kfpos_hip.hip -- HIP kernels (gfx950 / CDNA4) and the C ABI of include/kfpos.h.
- *
- * Execution model: ONE FILTER PER LANE, 64 filters per wavefront, one wavefront per workgroup.
- *  - The whole per-tag state (position, velocity, packed covariance: 21 / 36 / 45 doubles) lives in
- *    VGPRs/AGPRs for the duration of a step -- and across the epochs of a multi-epoch launch; every array
- *    index in kfpos_core.h is a compile-time constant after unrolling. At 65 536 tags there is exactly one
- *    wavefront per SIMD (1024 waves on 256 CUs x 4 SIMDs), so the 512-register file per lane is free to use.
- *    No kernel may spill to scratch (checked at build time, __graft_entry__.build()).
- *  - HBM layout is component-major ([component][tag]): lane l of a wave reads element
- *    base + tag0 + l, so every state / measurement access is one fully coalesced
- *    512-byte (f64) or 256-byte (f32 / int32) wave transaction, each byte touched once.
- *  - The epoch's measurements -- range in metres (the integer-mm wire value converted once, with the
- *    reference's exact `(double) mm / 1000`, Posgenerator.cpp:484), errorEstimation, working weight (1/e for
- *    the ML sweeps, 1/R for the IEKF sweeps) -- live in registers for 8 anchors (RegScratch) and per lane in
- *    LDS otherwise, [anchor][lane] (lane-consecutive 8-byte words: conflict-free ds_read_b64), with
- *    compile-time anchor loops for 16 anchors (StaticScratch) and a run-time loop for every other count. The
- *    inner sweeps (2-4 ML + 3-20 IEKF per step) then touch only registers / LDS + SGPRs, never HBM.
- *  - LDS also parks two 36-double objects that do not fit next to the rest: the predicted covariance of the
- *    planar filter's sensor-row update (CovSpill8) and the pseudo-inverse of the non-symmetric 6-state layout
- *    (Pinv6).
- *  - Anchor coordinates are wave-uniform: they travel in the kernel-argument segment and are read
- *    with scalar loads into SGPRs.
- *  - No MFMA: the largest dense object is 9x9 per filter; no cross-lane traffic at all: lanes are
- *    independent filters, so there is nothing to shuffle and no barrier in any kernel.
- *
- * Kernels: k_step_toa6 (KalmanFilterTOA.cpp:70-156), k_step_imu9 (KalmanFilterTOAIMU.cpp:100-195), k_step_planar
- * (KalmanFilter.cpp:224-321 with all five sensor entry points), k_step_ml (MLLocation.cpp:421-486), k_get_pose (the
- * getPose of each of them), k_rows_to_cols / k_cols_to_rows (layout turn of the host-buffer API).
+ * kfpos_hip.hip -- host side of libkfpos_hip.so: the handle, launch selection, the three ways in (synchronous
+ * host-buffer API, streaming slots, device-buffer API) and the C ABI of include/kfpos.h. The kernels live in
+ * kfpos_k_*.hip (kfpos_kernels.h says which is where); the RCCL pose gather in kfpos_comm.hip.
  */
-#include <hip/hip_runtime.h>
-
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -38,24 +11,7 @@
 #include <string>
 #include <vector>
 
-#define KFPOS_HD __host__ __device__
-#include "kfpos_core.h"
-/* A second copy of the per-tag arithmetic, contracted the way hipcc does by default (multiply-adds fused across
- * statements too), for ONE kernel: the 8-lanes-per-tag step of small banks (k_step_toa6_coop). The library is built with
- * -ffp-contract=on so that every one-tag-per-lane kernel rounds alike (Makefile); that kernel sums in another order
- * anyway (three DPP exchanges per partial sum), is nothing but one dependent chain, and runs 5 % faster with the chain
- * the freer contraction leaves (BASELINE configs[1]: 4.54 -> 4.29 us per epoch). */
-#pragma clang fp contract(fast)
-#undef KFPOS_CORE_H
-#undef KFPOS_CORE_ML_H
-#undef KFPOS_CORE_TOA6_H
-#undef KFPOS_CORE_IMU9_H
-#undef KFPOS_CORE_PLANAR_H
-namespace kfpos_chain {
-#include "kfpos_core.h"
-}
-#pragma clang fp contract(on)
-#include "kfpos_internal.h"
+#include "kfpos_kernels.h"
 
 std::string &kfpos_error_text() {
     thread_local std::string text;
@@ -63,946 +19,6 @@ std::string &kfpos_error_text() {
 }
 
 namespace {
-
-using namespace kfpos;
-
-constexpr int WAVE = 64; /* lanes per workgroup = one wavefront */
-
-enum StepMode : int { MODE_TOA = 0, MODE_IMU_ONLY = 1, MODE_FUSED = 2 };
-
-/* kernel arguments: everything wave-uniform, read through scalar loads */
-struct KArgs {
-    double anchors[KFPOS_MAX_ANCHORS * 3];
-    int T, A;
-    double accel_noise, jolt, cost_threshold;
-    int ignore_worst, top_n, use_init_pos, ml_variant;
-    int pair9;        /* 9-state kernel: two lanes per tag for the tail of the gain iteration (KFPOS_PAIR9=1; off by default: DESIGN 6a) */
-    /* planar filter configuration (kfpos_planar_config) */
-    int use_fixed_height, imu_fixed_cov_acc, imu_fixed_cov_w;
-    double px4_height, px4_arm_p1, px4_arm_p2, px4_cov_vel, px4_cov_gyro_z;
-    double imu_cov_acc, imu_cov_w, mag_offset, mag_cov;
-    double *platch;   /* [15][T] planar filter: latched PX4Flow (5), IMU (8), magnetometer (2) samples */
-    const double *sensor; /* planar sensor call: [C][T] sample of this call (C = 5 / 24 / 3 / 1) */
-    /* persistent state, component-major */
-    double *pos;      /* [3][T] */
-    double *vel;      /* [3][T] (9-state; always f64: the 9-state filter amplifies velocity rounding);
-                         planar filter: [4][T] = vx, vy, theta, omega */
-    void *P;          /* [SZ][T] real */
-    uint32_t *flags;  /* [T] */
-    void *imu_acc;    /* [3][T] real, latched sample (9-state) */
-    void *imu_cov;    /* [6][T] real, lower triangle {00,10,11,20,21,22} of the latched covariance */
-    /* epoch inputs */
-    const int32_t *ranges; /* [A][T] */
-    const void *err;       /* [A][T] real */
-    const double *dt;      /* [T] or null */
-    double dt_shared;
-    const void *accel;     /* [3][T] real */
-    const void *cov;       /* [9][T] real */
-    int mode, latch;
-    uint32_t *status;      /* [T] or null */
-    /* multi-epoch launches (kfpos_run_trace_dev): epoch s reads its inputs at base + s * stride (elements),
-     * dt_steps[s] is its shared dt. n_steps = 1 is the single-epoch case and uses dt / dt_shared. */
-    int n_steps;
-    long long stride_ranges, stride_err, stride_accel, stride_cov;
-    double *traj;          /* [n_steps][3][T] positions after each epoch, or null */
-    double dt_steps[KFPOS_TRACE_CHUNK];
-};
-
-/* Component-major arrays are addressed as (wave-uniform row base) + (32-bit lane offset): the row base
- * stays in SGPRs (global_load ... v_off, s[base]) and one VGPR serves every array, instead of a 64-bit
- * per-lane address kept alive for each of the 30-60 rows between the loads and the final stores. */
-template <typename REAL>
-__device__ inline double ldrow(const void *p, size_t row, size_t T, uint32_t t) {
-    return (double)(((const REAL *)p) + row * T)[t];
-}
-template <typename REAL>
-__device__ inline void strow(void *p, size_t row, size_t T, uint32_t t, double v) {
-    (((REAL *)p) + row * T)[t] = (REAL)v;
-}
-
-template <class P>
-__device__ inline P make_params_of(const KArgs &a) {
-    P pr;
-    pr.anchors = a.anchors;
-    pr.n_anchors = a.A;
-    pr.accel_noise = a.accel_noise;
-    pr.jolt = a.jolt;
-    pr.cost_threshold = a.cost_threshold;
-    pr.ignore_worst = a.ignore_worst;
-    pr.top_n = a.top_n;
-    pr.ml_variant = a.ml_variant;
-    pr.use_init_pos = a.use_init_pos;
-    pr.use_fixed_height = a.use_fixed_height;
-    pr.imu_fixed_cov_acc = a.imu_fixed_cov_acc;
-    pr.imu_fixed_cov_w = a.imu_fixed_cov_w;
-    pr.px4_height = a.px4_height;
-    pr.px4_arm_p1 = a.px4_arm_p1;
-    pr.px4_arm_p2 = a.px4_arm_p2;
-    pr.px4_cov_vel = a.px4_cov_vel;
-    pr.px4_cov_gyro_z = a.px4_cov_gyro_z;
-    pr.imu_cov_acc = a.imu_cov_acc;
-    pr.imu_cov_w = a.imu_cov_w;
-    pr.mag_offset = a.mag_offset;
-    pr.mag_cov = a.mag_cov;
-    return pr;
-}
-__device__ inline Params make_params(const KArgs &a) { return make_params_of<Params>(a); }
-
-/* Raw epoch of one tag as it sits in HBM: fetched one epoch ahead in multi-epoch launches, so its
- * latency hides behind the previous epoch's arithmetic. */
-template <typename MREAL, int AS>
-struct RawEpoch {
-    int32_t mm[AS];
-    MREAL e[AS];
-};
-template <typename MREAL, int AS>
-__device__ inline void fetch_epoch(const KArgs &a, size_t t, int s, RawEpoch<MREAL, AS> &raw) {
-    const int32_t *rp = a.ranges + (size_t)s * a.stride_ranges;
-    const MREAL *ep = (const MREAL *)a.err + (size_t)s * a.stride_err;
-#pragma unroll
-    for (int k = 0; k < AS; ++k) { /* all loads first: one latency, not AS of them */
-        raw.mm[k] = (rp + (size_t)k * a.T)[(uint32_t)t];
-        raw.e[k] = (ep + (size_t)k * a.T)[(uint32_t)t];
-    }
-}
-template <typename MREAL, int AS>
-__device__ inline void unpack_epoch(const RawEpoch<MREAL, AS> &raw, RegScratch<AS> &sc) {
-#pragma unroll
-    for (int k = 0; k < AS; ++k) {
-        sc.r[k] = raw.mm[k] > 0 ? kf_mm_to_m(raw.mm[k]) : 0.0; /* Posgenerator.cpp:483-484 */
-        sc.e[k] = (double)raw.e[k];
-        sc.w[k] = 0.0;
-    }
-}
-/* generic anchor count: epoch s -> per-lane LDS scratch */
-template <typename MREAL>
-__device__ inline Scratch stage_epoch_lds(const KArgs &a, double *lds, int lane, size_t t, int s) {
-    Scratch sc;
-    sc.r = lds + lane;
-    sc.e = lds + (size_t)a.A * WAVE + lane;
-    sc.w = lds + 2 * (size_t)a.A * WAVE + lane;
-    sc.stride = WAVE;
-    const int32_t *rp = a.ranges + (size_t)s * a.stride_ranges;
-    const MREAL *ep = (const MREAL *)a.err + (size_t)s * a.stride_err;
-    for (int k = 0; k < a.A; ++k) {
-        const int32_t mm = (rp + (size_t)k * a.T)[(uint32_t)t];
-        sc.r[k * WAVE] = mm > 0 ? kf_mm_to_m(mm) : 0.0;
-        sc.e[k * WAVE] = (double)(ep + (size_t)k * a.T)[(uint32_t)t];
-    }
-    return sc;
-}
-/* anchor count known at compile time: all 2 N loads first, then the conversions and the LDS stores */
-template <typename MREAL, int N>
-__device__ inline StaticScratch<N> stage_epoch_lds_n(const KArgs &a, double *lds, int lane, size_t t, int s) {
-    StaticScratch<N> sc;
-    sc.r = lds + lane;
-    sc.e = lds + (size_t)N * WAVE + lane;
-    sc.w = lds + 2 * (size_t)N * WAVE + lane;
-    sc.stride = WAVE;
-    RawEpoch<MREAL, N> raw;
-    fetch_epoch<MREAL, N>(a, t, s, raw);
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-        sc.r[k * WAVE] = raw.mm[k] > 0 ? kf_mm_to_m(raw.mm[k]) : 0.0;
-        sc.e[k * WAVE] = (double)raw.e[k];
-    }
-    return sc;
-}
-/* A wave-uniform epoch index the optimiser cannot see through: addresses derived from it are formed anew in every
- * epoch (a few scalar instructions) instead of living as two dozen running row pointers across the whole epoch loop,
- * where they exhaust the scalar registers and end up as spilled 64-bit per-lane addresses. */
-__device__ inline int opaque_uniform(int v) {
-    asm volatile("" : "+s"(v));
-    return v;
-}
-/* the same for the lane's tag index: its per-array 64-bit addresses are then formed where they are used instead of
- * being carried (spilled) across the epoch loop */
-__device__ inline size_t opaque_lane(size_t t) {
-    uint32_t v = (uint32_t)t;
-    asm volatile("" : "+v"(v));
-    return v;
-}
-/* the same with 4-byte errorEstimations kept as they are: LDS = r [N][lane] f64 | w [N][lane] f64 | e [N][lane] f32 */
-template <int N>
-__device__ inline StaticScratchF<N> stage_epoch_lds_nf(const KArgs &a, double *lds, int lane, size_t t, int s) {
-    StaticScratchF<N> sc;
-    sc.r = lds + lane;
-    sc.w = lds + (size_t)N * WAVE + lane;
-    sc.e = (float *)(lds + 2 * (size_t)N * WAVE) + lane;
-    sc.stride = WAVE;
-    RawEpoch<float, N> raw;
-    fetch_epoch<float, N>(a, t, s, raw);
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-        sc.r[k * WAVE] = raw.mm[k] > 0 ? kf_mm_to_m(raw.mm[k]) : 0.0;
-        sc.e[k * WAVE] = raw.e[k];
-    }
-    return sc;
-}
-/* doubles of LDS the epoch of a compile-time-count kernel takes per workgroup */
-template <typename MREAL, int N>
-constexpr size_t static_epoch_doubles() { return sizeof(MREAL) == 4 ? (size_t)N * WAVE * 5 / 2 : (size_t)N * WAVE * 3; }
-__device__ inline double epoch_dt(const KArgs &a, size_t t, int s) {
-    return a.n_steps > 1 ? a.dt_steps[s] : (a.dt ? a.dt[(uint32_t)t] : a.dt_shared);
-}
-
-/* a lane that sits a call out (dt < 0, or a dropped PX4Flow sample) still reports where its tag is: the trajectory /
- * pose output of the call carries the untouched position (what getPose at timeLag 0 would return) */
-__device__ inline void skipped_lane(const KArgs &a, size_t t, bool write) {
-    if (!write) return;
-    if (a.status) a.status[t] = ST_SKIPPED;
-    if (a.traj) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) (a.traj + (size_t)k * a.T)[(uint32_t)t] = (a.pos + (size_t)k * a.T)[(uint32_t)t];
-    }
-}
-
-/* ------------------------------------------------------------------ 6-state step kernel */
-/* amdgpu_waves_per_eu(1, 2): never trade registers for a third wave per SIMD -- the LDS-resident 16-anchor variant
- * fits in 137 VGPRs when asked to, and then runs 11 % slower than with the 227 it takes at two waves (measured). */
-template <bool SYMM, typename REAL, typename MREAL, int AS, int HEUR = 2>
-__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_step_toa6(const KArgs a) {
-    extern __shared__ double lds[];
-    const int lane = threadIdx.x;
-    const size_t t = (size_t)blockIdx.x * WAVE + lane;
-    if (t >= (size_t)a.T) return;
-    const size_t T = a.T;
-    const uint32_t t32 = (uint32_t)t;
-    const Params pr = make_params(a);
-    constexpr int NA = AS > 0 ? AS : 1;
-    if (a.n_steps == 1 && a.dt && a.dt[t] < 0.0) { /* no epoch for this tag in this call */
-        skipped_lane(a, t, true);
-        return;
-    }
-
-    /* Load order = order of first use: epoch and position feed the ML solve, the covariance is first
-     * touched after it (step_toa6), so its 21-36 loads stay in flight behind ~2-3 k instructions. */
-    RawEpoch<MREAL, NA> raw;
-    if constexpr (AS > 0) fetch_epoch<MREAL, AS>(a, t, 0, raw);
-    Tag6<SYMM> tg;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) tg.pos[k] = (a.pos + k * T)[t32];
-#pragma unroll
-    for (int k = 0; k < Cov<6, SYMM>::SZ; ++k) tg.P.a[k] = ldrow<REAL>(a.P, k, T, t32);
-
-    uint32_t s = 0;
-    for (int e = 0; e < a.n_steps; ++e) { /* the state stays in registers from epoch to epoch */
-        const double dt = epoch_dt(a, t, e);
-        if constexpr (AS > 0) {
-            RegScratch<AS> sc;
-            unpack_epoch<MREAL, AS>(raw, sc);
-            if (e + 1 < a.n_steps) fetch_epoch<MREAL, AS>(a, t, e + 1, raw); /* next epoch in flight */
-            s = step_toa6<SYMM, HEUR>(tg, sc, pr, dt);
-        } else if constexpr (AS < 0 && sizeof(MREAL) == 4) { /* compile-time count, epoch in LDS, 4-byte errorEstimations */
-            StaticScratchF<-AS> sc = stage_epoch_lds_nf<-AS>(a, lds, lane, t, e);
-            s = step_toa6<SYMM, HEUR>(tg, sc, pr, dt, lds + static_epoch_doubles<MREAL, -AS>() + lane, WAVE);
-        } else if constexpr (AS < 0) { /* compile-time count, epoch in LDS */
-            StaticScratch<-AS> sc = stage_epoch_lds_n<MREAL, -AS>(a, lds, lane, t, e);
-            s = step_toa6<SYMM, HEUR>(tg, sc, pr, dt, lds + static_epoch_doubles<MREAL, -AS>() + lane, WAVE);
-        } else {
-            Scratch sc = stage_epoch_lds<MREAL>(a, lds, lane, t, e);
-            s = step_toa6<SYMM, HEUR>(tg, sc, pr, dt, lds + 3 * (size_t)a.A * WAVE + lane, WAVE);
-        }
-        if (a.traj) { /* the pose a per-epoch caller would have read back (getPose at timeLag 0) */
-#pragma unroll
-            for (int k = 0; k < 3; ++k) (a.traj + ((size_t)e * 3 + k) * T)[t32] = tg.pos[k];
-        }
-        if constexpr (sizeof(REAL) == 4) { /* what n single-epoch launches would have kept in HBM */
-            if (e + 1 < a.n_steps) {
-#pragma unroll
-                for (int k = 0; k < Cov<6, SYMM>::SZ; ++k) tg.P.a[k] = (double)(float)tg.P.a[k];
-            }
-        }
-    }
-
-    bool fin = true;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        (a.pos + k * T)[t32] = tg.pos[k];
-        fin &= isfinite(tg.pos[k]);
-    }
-#pragma unroll
-    for (int k = 0; k < Cov<6, SYMM>::SZ; ++k) {
-        strow<REAL>(a.P, k, T, t32, tg.P.a[k]);
-        fin &= isfinite(tg.P.a[k]);
-    }
-    const bool waiting = !a.use_init_pos && isnan(tg.pos[0]); /* still waiting for its ML initialisation */
-    if (!fin && !waiting) s |= ST_NONFINITE;
-    a.flags[t] |= FL_STARTED;
-    if (a.status) a.status[t] = s;
-}
-
-/* The plain 8-anchor 6-state step (symmetric layout, no outlier heuristic) in at most 256 registers, for banks with
- * more wavefronts than the chip has SIMDs (> 65 536 tags). Left to itself the compiler gives the register-resident
- * kernel above 305 registers: one wavefront per SIMD, which is all a bank of up to 65 536 tags can use -- but a bank
- * of 131 072 tags (BASELINE configs[3] on 8 GPUs) then runs as two rounds of one wavefront per SIMD instead of one
- * round of two that fill each other's idle cycles. Here the epoch sits in LDS ([anchor][lane], compile-time loops 8
- * wide as above) and most of the covariance joins it while the ML solve runs (step_toa6<..., PARKN>): 19.5 KB per
- * wavefront, eight wavefronts per CU. Same arithmetic, same bits (tests/test_two_waves_gpu.py). */
-template <typename MREAL>
-constexpr int toa6_w2_park() { return sizeof(MREAL) == 4 ? 19 : 15; } /* what 160 KB / 8 leave next to the epoch */
-template <typename REAL, typename MREAL>
-__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_step_toa6_w2(const KArgs a) {
-    extern __shared__ double lds[];
-    const int lane = threadIdx.x;
-    const size_t t = (size_t)blockIdx.x * WAVE + lane;
-    if (t >= (size_t)a.T) return;
-    const size_t T = a.T;
-    const uint32_t t32 = (uint32_t)t;
-    const Params pr = make_params(a);
-    if (a.n_steps == 1 && a.dt && a.dt[t] < 0.0) { /* no epoch for this tag in this call */
-        skipped_lane(a, t, true);
-        return;
-    }
-    Tag6<true> tg;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) tg.pos[k] = (a.pos + k * T)[t32];
-#pragma unroll
-    for (int k = 0; k < Cov<6, true>::SZ; ++k) tg.P.a[k] = ldrow<REAL>(a.P, k, T, t32);
-    double *park = lds + static_epoch_doubles<MREAL, 8>() + lane;
-    constexpr int PARKN = toa6_w2_park<MREAL>();
-    uint32_t s = 0;
-    for (int e = 0; e < a.n_steps; ++e) {
-        const double dt = epoch_dt(a, opaque_lane(t), e);
-        if constexpr (sizeof(MREAL) == 4) {
-            StaticScratchF<8> sc = stage_epoch_lds_nf<8>(a, lds, lane, opaque_lane(t), opaque_uniform(e));
-            s = step_toa6<true, 0, PARKN>(tg, sc, pr, dt, park, WAVE);
-        } else {
-            StaticScratch<8> sc = stage_epoch_lds_n<MREAL, 8>(a, lds, lane, opaque_lane(t), opaque_uniform(e));
-            s = step_toa6<true, 0, PARKN>(tg, sc, pr, dt, park, WAVE);
-        }
-        if (a.traj) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) (a.traj + ((size_t)opaque_uniform(e) * 3 + k) * T)[t32] = tg.pos[k];
-        }
-        if constexpr (sizeof(REAL) == 4) { /* what n single-epoch launches would have kept in HBM */
-            if (e + 1 < a.n_steps) {
-#pragma unroll
-                for (int k = 0; k < Cov<6, true>::SZ; ++k) tg.P.a[k] = (double)(float)tg.P.a[k];
-            }
-        }
-    }
-    bool fin = true;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        (a.pos + k * T)[t32] = tg.pos[k];
-        fin &= isfinite(tg.pos[k]);
-    }
-#pragma unroll
-    for (int k = 0; k < Cov<6, true>::SZ; ++k) {
-        strow<REAL>(a.P, k, T, t32, tg.P.a[k]);
-        fin &= isfinite(tg.P.a[k]);
-    }
-    if (!fin) s |= ST_NONFINITE; /* (a symmetric-layout bank has a fixed start: no tag waits for an initialisation) */
-    a.flags[t] |= FL_STARTED;
-    if (a.status) a.status[t] = s;
-}
-
-/* ------------------------------------------------------------------ 6-state step kernel, small batches */
-/* One tag per group of 8 lanes, one anchor per lane (kfpos_core.h: CoopScratch): for banks of a few thousand tags
- * the chip is mostly empty and a step costs the instruction chain of one lane, so the anchor sweeps are spread
- * over the idle lanes (three DPP exchanges per partial sum) and the chain shrinks ~2.5x. Plain 6-state filter only:
- * fixed start (symmetric layout), no outlier heuristic, at most 8 anchors. Every lane of a group carries the tag's
- * whole state (identical bits); lane 0 of the group writes it back. */
-constexpr int COOP_LANES = 8;
-constexpr int COOP_TAGS_PER_WAVE = WAVE / COOP_LANES;
-
-template <typename REAL, typename MREAL>
-__global__ __launch_bounds__(WAVE) void k_step_toa6_coop(const KArgs a) {
-    __shared__ double s_anchor[COOP_LANES * 3];
-    const int lane = threadIdx.x, al = lane & (COOP_LANES - 1);
-    if (lane < COOP_LANES * 3) s_anchor[lane] = (lane < a.A * 3) ? a.anchors[lane] : 0.0; /* wave-uniform table -> LDS */
-    __syncthreads();
-    const size_t t = (size_t)blockIdx.x * COOP_TAGS_PER_WAVE + (lane >> 3);
-    if (t >= (size_t)a.T) return; /* whole groups only: the exchanges never cross a group */
-    const size_t T = a.T;
-    const uint32_t t32 = (uint32_t)t;
-    namespace kc = kfpos_chain::kfpos; /* the arithmetic with the freer contraction (top of this file) */
-    const kc::Params pr = make_params_of<kc::Params>(a);
-    if (a.n_steps == 1 && a.dt && a.dt[t] < 0.0) {
-        skipped_lane(a, t, al == 0);
-        return;
-    }
-    const bool has_anchor = al < a.A;
-    kc::CoopScratch sc;
-    sc.bx = s_anchor[3 * al]; sc.by = s_anchor[3 * al + 1]; sc.bz = s_anchor[3 * al + 2];
-    kc::Tag6<true> tg;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) tg.pos[k] = (a.pos + k * T)[t32];
-#pragma unroll
-    for (int k = 0; k < 21; ++k) tg.P.a[k] = ldrow<REAL>(a.P, k, T, t32);
-    int32_t mm = 0;
-    MREAL ee = (MREAL)1;
-    if (has_anchor) {
-        mm = (a.ranges + (size_t)al * T)[t32];
-        ee = ((const MREAL *)a.err + (size_t)al * T)[t32];
-    }
-    uint32_t s = 0;
-    for (int e = 0; e < a.n_steps; ++e) {
-        const double dt = epoch_dt(a, t, e);
-        sc.r = mm > 0 ? kc::kf_mm_to_m(mm) : 0.0;
-        sc.e = (double)ee;
-        sc.w = 0.0;
-        if (e + 1 < a.n_steps && has_anchor) { /* next epoch in flight */
-            mm = (a.ranges + (size_t)(e + 1) * a.stride_ranges + (size_t)al * T)[t32];
-            ee = ((const MREAL *)a.err + (size_t)(e + 1) * a.stride_err + (size_t)al * T)[t32];
-        }
-        s = kc::step_toa6<true, 0>(tg, sc, pr, dt);
-        if (a.traj && al == 0) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) (a.traj + ((size_t)e * 3 + k) * T)[t32] = tg.pos[k];
-        }
-        if constexpr (sizeof(REAL) == 4) {
-            if (e + 1 < a.n_steps) {
-#pragma unroll
-                for (int k = 0; k < 21; ++k) tg.P.a[k] = (double)(float)tg.P.a[k];
-            }
-        }
-    }
-    if (al != 0) return;
-    bool fin = true;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        (a.pos + k * T)[t32] = tg.pos[k];
-        fin &= isfinite(tg.pos[k]);
-    }
-#pragma unroll
-    for (int k = 0; k < 21; ++k) {
-        strow<REAL>(a.P, k, T, t32, tg.P.a[k]);
-        fin &= isfinite(tg.P.a[k]);
-    }
-    if (!fin) s |= ST_NONFINITE;
-    a.flags[t] |= FL_STARTED;
-    if (a.status) a.status[t] = s;
-}
-
-/* ------------------------------------------------------------------ standalone ML estimator kernel */
-template <typename REAL, typename MREAL, int AS>
-__global__ __launch_bounds__(WAVE) void k_step_ml(const KArgs a) {
-    extern __shared__ double lds[];
-    const int lane = threadIdx.x;
-    const size_t t = (size_t)blockIdx.x * WAVE + lane;
-    if (t >= (size_t)a.T) return;
-    const size_t T = a.T;
-    const uint32_t t32 = (uint32_t)t;
-    const Params pr = make_params(a);
-    if (a.n_steps == 1 && a.dt && a.dt[t] < 0.0) {
-        skipped_lane(a, t, true);
-        return;
-    }
-    /* _previousEstimation: the per-tag seed lives in the velocity slot of the handle, it is never updated */
-    double seed[3] = {1.0, 1.0, 4.0};
-    if (a.use_init_pos) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) seed[k] = (a.vel + k * T)[t32];
-    }
-    double pos[3], cov[6];
-    uint32_t s = 0;
-    for (int e = 0; e < a.n_steps; ++e) {
-        if constexpr (AS > 0) {
-            RawEpoch<MREAL, AS> raw;
-            fetch_epoch<MREAL, AS>(a, t, e, raw);
-            RegScratch<AS> sc;
-            unpack_epoch<MREAL, AS>(raw, sc);
-            s = step_ml(pos, cov, sc, pr, seed);
-        } else {
-            Scratch sc = stage_epoch_lds<MREAL>(a, lds, lane, t, e);
-            s = step_ml(pos, cov, sc, pr, seed);
-        }
-        if (a.traj && !(s & ST_UPDATE_SKIPPED)) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) (a.traj + ((size_t)e * 3 + k) * T)[t32] = pos[k];
-        }
-    }
-    if (!(s & ST_UPDATE_SKIPPED)) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) (a.pos + k * T)[t32] = pos[k];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) strow<REAL>(a.P, k, T, t32, cov[k]);
-    }
-    a.flags[t] |= FL_STARTED;
-    if (a.status) a.status[t] = s;
-}
-
-/* ------------------------------------------------------------------ 9-state step kernel */
-/* The acceleration sample is fetched one epoch ahead like the ranges. Its covariance is loaded and whitened ONCE per
- * launch: a multi-epoch launch always has one covariance array for all its epochs (stride_cov = 0: a sensor with a
- * fixed covariance); a trace with a covariance per epoch is replayed one epoch per launch (kfpos_run_trace_dev). */
-template <typename MREAL>
-struct RawImu {
-    MREAL acc[3];
-};
-template <typename MREAL>
-__device__ inline void fetch_imu(const KArgs &a, size_t t, int s, RawImu<MREAL> &raw) {
-    const MREAL *ap = (const MREAL *)a.accel + (size_t)s * a.stride_accel;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) raw.acc[k] = (ap + (size_t)k * a.T)[(uint32_t)t];
-}
-template <typename MREAL>
-__device__ inline void fetch_imu_cov(const KArgs &a, size_t t, int s, MREAL raw[9]) {
-    const MREAL *cp = (const MREAL *)a.cov + (size_t)s * a.stride_cov;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) raw[k] = (cp + (size_t)k * a.T)[(uint32_t)t];
-}
-template <typename MREAL>
-__device__ inline void latch_imu_cov(const KArgs &a, size_t T, uint32_t t32, const double cv[9]) {
-    strow<MREAL>(a.imu_cov, 0, T, t32, cv[0]);
-    strow<MREAL>(a.imu_cov, 1, T, t32, cv[3]);
-    strow<MREAL>(a.imu_cov, 2, T, t32, cv[4]);
-    strow<MREAL>(a.imu_cov, 3, T, t32, cv[6]);
-    strow<MREAL>(a.imu_cov, 4, T, t32, cv[7]);
-    strow<MREAL>(a.imu_cov, 5, T, t32, cv[8]);
-}
-
-/* RANGING = false: the IMU-only call (MODE_IMU_ONLY), a kernel of its own */
-template <typename REAL, typename MREAL, int AS, bool RANGING = true>
-__global__ __launch_bounds__(WAVE) void k_step_imu9(const KArgs a) {
-    extern __shared__ double lds[];
-    const int lane = threadIdx.x;
-    const size_t t = (size_t)blockIdx.x * WAVE + lane;
-    if (t >= (size_t)a.T) return;
-    const size_t T = a.T;
-    const uint32_t t32 = (uint32_t)t;
-    Params pr = make_params(a);
-    constexpr bool has_ranging = RANGING;
-    /* the next epoch's measurements are fetched one epoch AHEAD, behind the current epoch's arithmetic -- in the
-     * KFPOS_STORE_MIXED instantiation (the bench configuration); the other two (8-byte measurements: 22 more registers
-     * per lane across the whole step; 4-byte covariance: its rounding code) do not have the registers for that (they
-     * spill), so they fetch between two epochs instead */
-    constexpr bool AHEAD = sizeof(MREAL) == 4 && sizeof(REAL) == 8;
-    const bool fresh_imu = a.mode != MODE_TOA;
-    constexpr int NA = AS > 0 ? AS : 1;
-    if (a.n_steps == 1 && a.dt && a.dt[t32] < 0.0) { /* no epoch / sample for this tag in this call */
-        skipped_lane(a, t, true);
-        return;
-    }
-
-    /* load order = order of first use (see k_step_toa6): epoch, position, velocity, IMU sample, then the
-     * 45 covariance entries, which are not needed until the ML solve is over */
-    RawEpoch<MREAL, NA> raw;
-    RawImu<MREAL> rawi;
-    if constexpr (AS > 0) {
-        if (has_ranging) fetch_epoch<MREAL, AS>(a, t, 0, raw);
-    }
-    Tag9 tg;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        tg.pos[k] = (a.pos + k * T)[t32];
-        tg.vel[k] = (a.vel + k * T)[t32];
-    }
-    uint32_t fl = a.flags[t32];
-    /* the covariance and B^-1 wait in LDS while the gain iteration runs, the accelerometer whitener for the whole
-     * launch: [78][lane], behind the generic kernel's epoch scratch */
-    const CovPark9 park{lds + ((AS == 0 && has_ranging) ? 3 * (size_t)a.A * WAVE : 0) + lane, WAVE};
-    Imu imu;
-    imu.has = false;
-    imu.ci = park.a + 66 * WAVE;
-    imu.ci_stride = WAVE;
-    if constexpr (AS == 8 && RANGING) { /* the anchor table once more, where lanes can index it one by one (iekf9_pairs) */
-        if (a.pair9) {
-            double *tab = lds + 78 * WAVE;
-#pragma unroll
-            for (int k = 0; k < 24; ++k) tab[k] = a.anchors[k]; /* (every lane writes the same 24 numbers) */
-            pr.pair_anchor_tab = tab;
-        }
-    }
-    double cv[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    MREAL rawc[9];
-    if (fresh_imu) {
-        fetch_imu<MREAL>(a, t, 0, rawi);
-        fetch_imu_cov<MREAL>(a, t, 0, rawc);
-    } else if (fl & FL_HAS_IMU) { /* re-fuse the latched sample (KalmanFilterTOAIMU.cpp:68-72) */
-        imu.has = true;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) imu.acc[k] = ldrow<MREAL>(a.imu_acc, k, T, t32);
-        cv[0] = ldrow<MREAL>(a.imu_cov, 0, T, t32);
-        cv[3] = ldrow<MREAL>(a.imu_cov, 1, T, t32);
-        cv[4] = ldrow<MREAL>(a.imu_cov, 2, T, t32);
-        cv[6] = ldrow<MREAL>(a.imu_cov, 3, T, t32);
-        cv[7] = ldrow<MREAL>(a.imu_cov, 4, T, t32);
-        cv[8] = ldrow<MREAL>(a.imu_cov, 5, T, t32);
-    }
-#pragma unroll
-    for (int k = 0; k < 45; ++k) tg.P.a[k] = ldrow<REAL>(a.P, k, T, t32);
-    if (fresh_imu) { /* the covariance of the first (usually: of every) epoch of this launch */
-        imu.has = true;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) cv[k] = (double)rawc[k];
-        if (a.latch) latch_imu_cov<MREAL>(a, T, t32, cv);
-    }
-    if (imu.has) imu_whitener(cv, imu.ci, imu.ci_stride);
-
-
-    uint32_t s = 0;
-    for (int e = 0; e < a.n_steps; ++e) { /* the state stays in registers from epoch to epoch */
-        const double dt = epoch_dt(a, t, e);
-        if (fresh_imu) { /* fresh sample: newIMUMeasurement latches it (KalmanFilterTOAIMU.cpp:78-89) */
-#pragma unroll
-            for (int k = 0; k < 3; ++k) imu.acc[k] = (double)rawi.acc[k];
-            if (e + 1 < a.n_steps) {
-                if constexpr (AHEAD) fetch_imu<MREAL>(a, opaque_lane(t), opaque_uniform(e + 1), rawi);
-            }
-        }
-        if constexpr (AS > 0) {
-            RegScratch<AS> sc;
-            if (has_ranging) {
-                unpack_epoch<MREAL, AS>(raw, sc);
-                if (e + 1 < a.n_steps) {
-                    if constexpr (AHEAD) fetch_epoch<MREAL, AS>(a, opaque_lane(t), opaque_uniform(e + 1), raw);
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < AS; ++k) sc.r[k] = sc.e[k] = sc.w[k] = 0.0;
-            }
-            s = step_imu9<RANGING>(tg, sc, pr, dt, imu, park);
-            if constexpr (!AHEAD) { /* 8-byte measurements: the next epoch is fetched when this one is over */
-                if (e + 1 < a.n_steps) {
-                    if (fresh_imu) fetch_imu<MREAL>(a, opaque_lane(t), opaque_uniform(e + 1), rawi);
-                    if (has_ranging) fetch_epoch<MREAL, AS>(a, opaque_lane(t), opaque_uniform(e + 1), raw);
-                }
-            }
-        } else {
-            Scratch sc{nullptr, nullptr, nullptr, WAVE};
-            if (has_ranging) sc = stage_epoch_lds<MREAL>(a, lds, lane, t, opaque_uniform(e));
-            s = step_imu9<RANGING>(tg, sc, pr, dt, imu, park);
-            if constexpr (!AHEAD) { /* the ranges are staged per epoch above; the next accelerometer sample is not */
-                if (e + 1 < a.n_steps && fresh_imu) fetch_imu<MREAL>(a, opaque_lane(t), opaque_uniform(e + 1), rawi);
-            }
-        }
-        if (a.traj) { /* the pose a per-epoch caller would have read back (getPose at timeLag 0) */
-#pragma unroll
-            for (int k = 0; k < 3; ++k) (a.traj + ((size_t)opaque_uniform(e) * 3 + k) * T)[t32] = tg.pos[k];
-        }
-        if constexpr (sizeof(REAL) == 4) { /* what n single-epoch launches would have kept in HBM */
-            if (e + 1 < a.n_steps) {
-#pragma unroll
-                for (int k = 0; k < 45; ++k) tg.P.a[k] = (double)(float)tg.P.a[k];
-            }
-        }
-    }
-
-    if (fresh_imu && a.latch) { /* the last epoch's sample stays latched (lastImuMeasurement, KalmanFilterTOAIMU.cpp:78-89) */
-#pragma unroll
-        for (int k = 0; k < 3; ++k) strow<MREAL>(a.imu_acc, k, T, t32, imu.acc[k]);
-        fl |= FL_HAS_IMU;
-    }
-    bool fin = true;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        (a.pos + k * T)[t32] = tg.pos[k];
-        (a.vel + k * T)[t32] = tg.vel[k];
-        fin &= isfinite(tg.pos[k]) & isfinite(tg.vel[k]);
-    }
-#pragma unroll
-    for (int k = 0; k < 45; ++k) {
-        strow<REAL>(a.P, k, T, t32, tg.P.a[k]);
-        fin &= isfinite(tg.P.a[k]);
-    }
-    const bool waiting = !a.use_init_pos && isnan(tg.pos[0]);
-    if (!fin && !waiting) s |= ST_NONFINITE;
-    a.flags[t32] = fl | FL_STARTED;
-    if (a.status) a.status[t32] = s;
-}
-
-/* ------------------------------------------------------------------ 8-state planar step kernel */
-/* KalmanFilter (ALGORITHM_KF). a.mode: 0 = ranging epoch (carries whatever the tag has latched), 1..4 = one of
- * the four other sensor entry points (KFPOS_SENSOR_*), which latch their sample and run an update without
- * ranging rows. SENS = false is the ranging-only bank: no latch traffic, closed-form 2x2 update. Flags word:
- * bit 0 started, bits 5..7 = latched PX4Flow / IMU / magnetometer. */
-constexpr int PLANAR_HAS_SHIFT = 4;
-constexpr int LATCH_ROWS = 15;
-
-template <bool SENS, typename REAL, typename MREAL, int AS>
-__global__ __launch_bounds__(WAVE) void k_step_planar(const KArgs a) {
-    extern __shared__ double lds[];
-    const int lane = threadIdx.x;
-    const size_t t = (size_t)blockIdx.x * WAVE + lane;
-    if (t >= (size_t)a.T) return;
-    const size_t T = a.T;
-    const uint32_t t32 = (uint32_t)t;
-    const Params pr = make_params(a);
-    const int kind = a.mode;
-    const bool has_ranging = kind == 0;
-    constexpr int NA = AS > 0 ? AS : 1;
-    if (a.n_steps == 1 && a.dt && a.dt[t] < 0.0) { /* no epoch / sample for this tag in this call */
-        skipped_lane(a, t, true);
-        return;
-    }
-    RawEpoch<MREAL, NA> raw;
-    if constexpr (AS > 0) {
-        if (has_ranging) fetch_epoch<MREAL, AS>(a, t, 0, raw);
-    }
-    Tag8 tg;
-    tg.xy[0] = (a.pos + 0 * T)[t32];
-    tg.xy[1] = (a.pos + 1 * T)[t32];
-    tg.z = (a.pos + 2 * T)[t32];
-    tg.vel[0] = (a.vel + 0 * T)[t32];
-    tg.vel[1] = (a.vel + 1 * T)[t32];
-    tg.ang = (a.vel + 2 * T)[t32];
-    tg.om = (a.vel + 3 * T)[t32];
-    uint32_t fl = a.flags[t];
-    Latch8 lt;
-    lt.has = SENS ? ((fl >> PLANAR_HAS_SHIFT) & (ROW_PX4 | ROW_IMU | ROW_MAG)) : 0u;
-#pragma unroll
-    for (int k = 0; k < 5; ++k) lt.px4[k] = 0.0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) lt.imu[k] = 0.0;
-    lt.mag[0] = lt.mag[1] = 0.0;
-    uint32_t rows = ROW_RANGING;
-    if constexpr (SENS) {
-        /* this call's sample (KalmanFilter.cpp:102-229); a PX4Flow sample of quality 0 is dropped on entry */
-        if (kind == KFPOS_SENSOR_PX4FLOW) {
-            double f[5], m[5];
-#pragma unroll
-            for (int k = 0; k < 5; ++k) f[k] = (a.sensor + k * T)[t32];
-            if (!px4_sample(pr, f, m)) {
-                skipped_lane(a, t, true);
-                return;
-            }
-#pragma unroll
-            for (int k = 0; k < 5; ++k) { lt.px4[k] = m[k]; (a.platch + k * T)[t32] = m[k]; }
-            lt.has |= ROW_PX4;
-            rows = ROW_PX4;
-        } else if (kind == KFPOS_SENSOR_IMU) {
-            double w3[3], cw[9], la[3], ca[9];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) { w3[k] = (a.sensor + k * T)[t32]; la[k] = (a.sensor + (12 + k) * T)[t32]; }
-#pragma unroll
-            for (int k = 0; k < 9; ++k) { cw[k] = (a.sensor + (3 + k) * T)[t32]; ca[k] = (a.sensor + (15 + k) * T)[t32]; }
-            imu_sample8(pr, w3, cw, la, ca, lt.imu);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) (a.platch + (5 + k) * T)[t32] = lt.imu[k];
-            lt.has |= ROW_IMU;
-            rows = ROW_IMU;
-        } else if (kind == KFPOS_SENSOR_MAG || kind == KFPOS_SENSOR_COMPASS) {
-            if (kind == KFPOS_SENSOR_MAG)
-                lt.mag[0] = atan2((a.sensor + 1 * T)[t32], (a.sensor + 0 * T)[t32]) - pr.mag_offset; /* :188 */
-            else
-                lt.mag[0] = normalize_angle(a.sensor[t32]); /* :207 */
-            lt.mag[1] = pr.mag_cov;
-            (a.platch + 13 * T)[t32] = lt.mag[0];
-            (a.platch + 14 * T)[t32] = lt.mag[1];
-            const uint32_t before = lt.has;
-            lt.has |= ROW_MAG;
-            rows = kind == KFPOS_SENSOR_MAG ? ROW_MAG : (ROW_MAG | (before & (ROW_PX4 | ROW_IMU)));
-        } else {
-            rows = ROW_RANGING | lt.has; /* newTOAMeasurement: the latched samples ride along (:84-98) */
-        }
-        /* latched samples this call carries but did not bring itself */
-        if ((rows & ROW_PX4) && kind != KFPOS_SENSOR_PX4FLOW) {
-#pragma unroll
-            for (int k = 0; k < 5; ++k) lt.px4[k] = (a.platch + k * T)[t32];
-        }
-        if ((rows & ROW_IMU) && kind != KFPOS_SENSOR_IMU) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) lt.imu[k] = (a.platch + (5 + k) * T)[t32];
-        }
-        if ((rows & ROW_MAG) && kind == 0) {
-            lt.mag[0] = (a.platch + 13 * T)[t32];
-            lt.mag[1] = (a.platch + 14 * T)[t32];
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 36; ++k) tg.P.a[k] = ldrow<REAL>(a.P, k, T, t32);
-
-    /* SENS: the predicted covariance is parked in LDS, [36][lane], behind the generic kernel's epoch scratch */
-    const CovSpill8 park{lds + (AS < 0 ? 3 * (size_t)(-AS) * WAVE : ((AS == 0 && has_ranging) ? 3 * (size_t)a.A * WAVE : 0)) + lane, WAVE};
-    uint32_t s = 0;
-    for (int e = 0; e < a.n_steps; ++e) { /* the state stays in registers from epoch to epoch */
-        const double dt = epoch_dt(a, t, e);
-        if constexpr (AS > 0) {
-            RegScratch<AS> sc;
-            if (has_ranging) {
-                unpack_epoch<MREAL, AS>(raw, sc);
-                if (e + 1 < a.n_steps) fetch_epoch<MREAL, AS>(a, t, e + 1, raw);
-            } else {
-#pragma unroll
-                for (int k = 0; k < AS; ++k) sc.r[k] = sc.e[k] = sc.w[k] = 0.0;
-            }
-            s = step_planar8<SENS>(tg, sc, pr, dt, rows, lt, park);
-        } else if constexpr (AS < 0) { /* compile-time anchor loops over the LDS-resident epoch (ranging epochs only) */
-            StaticScratch<-AS> sc = stage_epoch_lds_n<MREAL, -AS>(a, lds, lane, t, e);
-            s = step_planar8<SENS>(tg, sc, pr, dt, rows, lt, park);
-        } else {
-            Scratch sc{nullptr, nullptr, nullptr, WAVE};
-            if (has_ranging) sc = stage_epoch_lds<MREAL>(a, lds, lane, t, e);
-            s = step_planar8<SENS>(tg, sc, pr, dt, rows, lt, park);
-        }
-        if (a.traj) { /* the pose a per-epoch caller would have read back (getPose at timeLag 0) */
-            (a.traj + ((size_t)e * 3 + 0) * T)[t32] = tg.xy[0];
-            (a.traj + ((size_t)e * 3 + 1) * T)[t32] = tg.xy[1];
-            (a.traj + ((size_t)e * 3 + 2) * T)[t32] = tg.z;
-        }
-        if constexpr (sizeof(REAL) == 4) { /* what n single-epoch launches would have kept in HBM */
-            if (e + 1 < a.n_steps) {
-#pragma unroll
-                for (int k = 0; k < 36; ++k) tg.P.a[k] = (double)(float)tg.P.a[k];
-            }
-        }
-    }
-
-    bool fin = isfinite(tg.xy[0]) & isfinite(tg.xy[1]) & isfinite(tg.z) & isfinite(tg.vel[0]) & isfinite(tg.vel[1]) &
-               isfinite(tg.ang) & isfinite(tg.om);
-    (a.pos + 0 * T)[t32] = tg.xy[0];
-    (a.pos + 1 * T)[t32] = tg.xy[1];
-    (a.pos + 2 * T)[t32] = tg.z;
-    (a.vel + 0 * T)[t32] = tg.vel[0];
-    (a.vel + 1 * T)[t32] = tg.vel[1];
-    (a.vel + 2 * T)[t32] = tg.ang;
-    (a.vel + 3 * T)[t32] = tg.om;
-#pragma unroll
-    for (int k = 0; k < 36; ++k) {
-        strow<REAL>(a.P, k, T, t32, tg.P.a[k]);
-        fin &= isfinite(tg.P.a[k]);
-    }
-    const bool waiting = !a.use_init_pos && isnan(tg.xy[0]);
-    if (!fin && !waiting) s |= ST_NONFINITE;
-    fl |= FL_STARTED;
-    if constexpr (SENS) fl |= lt.has << PLANAR_HAS_SHIFT;
-    a.flags[t] = fl;
-    if (a.status) a.status[t] = s;
-}
-
-/* ------------------------------------------------------------------ pose kernel (getPose) */
-struct PoseArgs {
-    int T, model, full;
-    double accel_noise, jolt, dt_ahead;
-    const double *dt_each; /* [T] per-tag extrapolation time, or null to use dt_ahead */
-    const double *pos_in;
-    const double *vel_in;
-    const void *P;
-    const uint32_t *flags;
-    double *pos, *cov, *vel; /* [3][T], [9][T], [3][T]; any may be null */
-    double *full_x, *full_P; /* [n][T], [n*n][T] predicted state / covariance (row-major index first), or null */
-    uint32_t *status;
-};
-
-template <int MODEL, bool SYMM, typename REAL>
-__global__ __launch_bounds__(WAVE) void k_get_pose(const PoseArgs a) {
-    const size_t t = (size_t)blockIdx.x * WAVE + threadIdx.x;
-    if (t >= (size_t)a.T) return;
-    const size_t T = a.T;
-    const uint32_t t32 = (uint32_t)t;
-    double pos[3], vel[3] = {0, 0, 0}, cov[9];
-    uint32_t s = 0;
-    const double ahead = a.dt_each ? a.dt_each[t] : a.dt_ahead;
-    if (!(a.flags[t] & FL_STARTED)) {
-        s = ST_NOT_STARTED;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) pos[k] = vel[k] = NAN;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) cov[k] = NAN;
-        if (a.full_P) {
-            constexpr int N = MODEL == 6 ? 6 : (MODEL == 3 ? 3 : (MODEL == 8 ? 8 : 9));
-#pragma unroll
-            for (int i = 0; i < N; ++i) (a.full_x + i * T)[t32] = NAN;
-            for (int i = 0; i < N * N; ++i) (a.full_P + (size_t)i * T)[t32] = NAN;
-        }
-    } else if (MODEL == 3) { /* MLLocation::getPose: the estimate as it is */
-#pragma unroll
-        for (int k = 0; k < 3; ++k) pos[k] = (a.pos_in + k * T)[t32];
-        const double c[6] = {ldrow<REAL>(a.P, 0, T, t32), ldrow<REAL>(a.P, 1, T, t32), ldrow<REAL>(a.P, 2, T, t32),
-                             ldrow<REAL>(a.P, 3, T, t32), ldrow<REAL>(a.P, 4, T, t32), ldrow<REAL>(a.P, 5, T, t32)};
-        cov[0] = c[0]; cov[1] = c[1]; cov[2] = c[2]; cov[3] = c[1]; cov[4] = c[3]; cov[5] = c[4];
-        cov[6] = c[2]; cov[7] = c[4]; cov[8] = c[5];
-        if (a.full_P) {
-#pragma unroll
-            for (int i = 0; i < 3; ++i) (a.full_x + i * T)[t32] = pos[i];
-#pragma unroll
-            for (int i = 0; i < 9; ++i) (a.full_P + (size_t)i * T)[t32] = cov[i];
-        }
-    } else if (MODEL == 8) { /* KalmanFilter::getPose, KalmanFilter.cpp:709-745 */
-        Tag8 tg;
-        tg.xy[0] = (a.pos_in + 0 * T)[t32];
-        tg.xy[1] = (a.pos_in + 1 * T)[t32];
-        tg.z = (a.pos_in + 2 * T)[t32];
-        tg.vel[0] = (a.vel_in + 0 * T)[t32];
-        tg.vel[1] = (a.vel_in + 1 * T)[t32];
-        tg.ang = (a.vel_in + 2 * T)[t32];
-        tg.om = (a.vel_in + 3 * T)[t32];
-#pragma unroll
-        for (int k = 0; k < 36; ++k) tg.P.a[k] = ldrow<REAL>(a.P, k, T, t32);
-        double x8[8];
-        Cov<8, true> Pp;
-        pose8(tg, ahead, a.accel_noise, a.jolt, x8, Pp);
-        pos[0] = x8[0]; pos[1] = x8[1]; pos[2] = tg.z;
-        vel[0] = x8[2]; vel[1] = x8[3]; vel[2] = 0.0;
-        /* position block of stateToPose's 6x6: eye * 0.01 with the xy block of P (:349-354) */
-        cov[0] = Pp(0, 0); cov[1] = Pp(0, 1); cov[2] = 0.0;
-        cov[3] = Pp(0, 1); cov[4] = Pp(1, 1); cov[5] = 0.0;
-        cov[6] = 0.0; cov[7] = 0.0; cov[8] = 0.01;
-        if (a.full_P) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                (a.full_x + i * T)[t32] = x8[i];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) (a.full_P + (size_t)(i * 8 + j) * T)[t32] = Pp(i, j);
-            }
-        }
-    } else if (MODEL == 6) {
-        Tag6<SYMM> tg;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) tg.pos[k] = (a.pos_in + k * T)[t32];
-#pragma unroll
-        for (int k = 0; k < Cov<6, SYMM>::SZ; ++k) tg.P.a[k] = ldrow<REAL>(a.P, k, T, t32);
-        pose6<SYMM>(tg, ahead, a.accel_noise, pos, cov);
-        if (a.full_P) { /* the whole predicted covariance, as getPose computes it (KalmanFilterTOA.cpp:467-468) */
-            predict6(tg.P, ahead, a.accel_noise);
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                (a.full_x + i * T)[t32] = i < 3 ? tg.pos[i] : 0.0;
-#pragma unroll
-                for (int j = 0; j < 6; ++j) (a.full_P + (size_t)(i * 6 + j) * T)[t32] = tg.P(i, j);
-            }
-        }
-    } else {
-        Tag9 tg;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            tg.pos[k] = (a.pos_in + k * T)[t32];
-            tg.vel[k] = (a.vel_in + k * T)[t32];
-        }
-#pragma unroll
-        for (int k = 0; k < 45; ++k) tg.P.a[k] = ldrow<REAL>(a.P, k, T, t32);
-        pose9(tg, ahead, a.jolt, pos, vel, cov);
-        if (a.full_P) { /* KalmanFilterTOAIMU.cpp:503-506 */
-            predict9(tg.P, ahead, a.jolt);
-#pragma unroll
-            for (int i = 0; i < 9; ++i) {
-                (a.full_x + i * T)[t32] = i < 3 ? pos[i] : (i < 6 ? vel[i - 3] : 0.0);
-#pragma unroll
-                for (int j = 0; j < 9; ++j) (a.full_P + (size_t)(i * 9 + j) * T)[t32] = tg.P(i, j);
-            }
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        if (a.pos) (a.pos + k * T)[t32] = pos[k];
-        if (a.vel) (a.vel + k * T)[t32] = vel[k];
-    }
-    if (a.cov) {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) (a.cov + k * T)[t32] = cov[k];
-    }
-    if (a.status) a.status[t] = s;
-}
-
-/* ------------------------------------------------------------------ layout kernels of the host-buffer API */
-/* The host API takes and returns row-major [tag][component] arrays (one row per reference call); the step kernels
- * want [component][tag]. The turn is done on the device, next to one plain copy per array, instead of element by
- * element on the CPU. E = 4- or 8-byte element. */
-template <typename E>
-__global__ __launch_bounds__(256) void k_rows_to_cols(const E *src, E *dst, int T, int C) {
-    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= (size_t)T) return;
-    for (int c = 0; c < C; ++c) dst[(size_t)c * T + t] = src[t * C + c];
-}
-template <typename E>
-__global__ __launch_bounds__(256) void k_cols_to_rows(const E *src, E *dst, int T, int C) {
-    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= (size_t)T) return;
-    for (int c = 0; c < C; ++c) dst[t * C + c] = src[(size_t)c * T + t];
-}
 
 /* ------------------------------------------------------------------ host side */
 #define g_err (kfpos_error_text())
@@ -1071,7 +87,6 @@ void fill_args(const kfpos_handle *h, KArgs &a) {
     a.traj = nullptr;
 }
 
-typedef void (*step_kernel_t)(const KArgs);
 
 /* Anchor-count specialisation. 8 anchors (BASELINE configs 2-4): epoch in registers (RegScratch), returns 8. 16 anchors
  * (config 5, 6-state): a register-resident epoch costs 96 more live registers and spills to scratch, which is no faster
@@ -1096,74 +111,20 @@ int static_anchors(const kfpos_handle *h) {
     return 0;
 }
 
-template <bool SYMM, typename REAL, typename MREAL>
-step_kernel_t toa6_kernel(int as, int heur, bool two_waves = false) {
-    /* heur: 0 = the bank has no outlier heuristic (BASELINE configs 2 and 4), 1 = top-N only (config 5), 2 = leave-one-out
-     * (with or without top-N). 0 and 1 get instantiations with no leave-one-out loop compiled in: 13 % faster at 8 anchors */
-    if constexpr (SYMM) {
-        if (as == 8 && heur == 0 && two_waves) return k_step_toa6_w2<REAL, MREAL>;
-        if (as == 8) return heur ? k_step_toa6<true, REAL, MREAL, 8> : k_step_toa6<true, REAL, MREAL, 8, 0>;
-    } else {
-        /* non-symmetric layout (ML initialisation): its SVD path needs the registers a resident epoch would take
-         * (148-180 bytes/lane of scratch otherwise), so the 8-anchor epoch goes to LDS, loops still compile-time */
-        if (as == 8) return heur ? k_step_toa6<false, REAL, MREAL, -8> : k_step_toa6<false, REAL, MREAL, -8, 0>;
-    }
-    if (as == -16) return heur == 1 ? k_step_toa6<SYMM, REAL, MREAL, -16, 1> : k_step_toa6<SYMM, REAL, MREAL, -16>;
-    return heur ? k_step_toa6<SYMM, REAL, MREAL, 0> : k_step_toa6<SYMM, REAL, MREAL, 0, 0>;
-}
-template <typename REAL, typename MREAL>
-step_kernel_t imu9_kernel(int as, bool ranging) {
-    if (!ranging) return k_step_imu9<REAL, MREAL, 0, false>; /* no epoch: the anchor count plays no role */
-    if (as == 8) return k_step_imu9<REAL, MREAL, 8>;
-    return k_step_imu9<REAL, MREAL, 0>;
-}
-
-template <typename REAL, typename MREAL>
-step_kernel_t ml_kernel(int as) {
-    if (as == 8) return k_step_ml<REAL, MREAL, 8>;
-    return k_step_ml<REAL, MREAL, 0>;
-}
-
-/* With sensor rows the register-resident epoch of the 8-anchor specialisation no longer fits (measured: 212-244
- * bytes/lane of scratch), so those banks always run the LDS-staged kernel. */
-template <bool SENS, typename REAL, typename MREAL>
-step_kernel_t planar_kernel(int as) {
-    if constexpr (!SENS) {
-        if (as == 8) return k_step_planar<false, REAL, MREAL, 8>;
-    } else {
-        if (as == 8) return k_step_planar<true, REAL, MREAL, -8>; /* epoch in LDS, anchor loops compile-time */
-    }
-    return k_step_planar<SENS, REAL, MREAL, 0>;
-}
-template <bool SENS>
-step_kernel_t planar_kernel_st(int st, int as) {
-    return st == KFPOS_STORE_F32 ? planar_kernel<SENS, float, float>(as)
-         : st == KFPOS_STORE_MIXED ? planar_kernel<SENS, double, float>(as) : planar_kernel<SENS, double, double>(as);
-}
-
 step_kernel_t step_kernel(const kfpos_handle *h, bool sensor_call = false, bool imu_only = false) {
     const int st = h->cfg.storage, as = (h->force_generic || sensor_call) ? 0 : static_anchors(h);
-    if (h->cfg.model == KFPOS_MODEL_PLANAR)
-        return (h->planar_sensors || sensor_call) ? planar_kernel_st<true>(st, as) : planar_kernel_st<false>(st, as);
-    if (h->cfg.model == KFPOS_MODEL_ML)
-        return st == KFPOS_STORE_F32 ? ml_kernel<float, float>(as)
-             : st == KFPOS_STORE_MIXED ? ml_kernel<double, float>(as) : ml_kernel<double, double>(as);
-    if (h->coop)
-        return st == KFPOS_STORE_F32 ? k_step_toa6_coop<float, float>
-             : st == KFPOS_STORE_MIXED ? k_step_toa6_coop<double, float> : k_step_toa6_coop<double, double>;
+    if (h->cfg.model == KFPOS_MODEL_PLANAR) return kfpos_k::planar_kernel(st, h->planar_sensors || sensor_call, as);
+    if (h->cfg.model == KFPOS_MODEL_ML) return kfpos_k::ml_kernel(st, as);
+    if (h->coop) return kfpos_k::toa6_coop_kernel(st);
     if (h->cfg.model == KFPOS_MODEL_TOA) {
+        /* heur: 0 = the bank has no outlier heuristic (BASELINE configs 2 and 4), 1 = top-N only (config 5), 2 =
+         * leave-one-out (with or without top-N) */
         const int heur = h->cfg.ignore_worst != 0 ? 2 : (h->cfg.top_n != 0 ? 1 : 0);
-        if (h->full)
-            return st == KFPOS_STORE_F32 ? toa6_kernel<false, float, float>(as, heur)
-                 : st == KFPOS_STORE_MIXED ? toa6_kernel<false, double, float>(as, heur)
-                                           : toa6_kernel<false, double, double>(as, heur);
-        const bool w2 = toa6_two_waves(h); /* more wavefronts than SIMDs: the 256-register build of the plain kernel */
-        return st == KFPOS_STORE_F32 ? toa6_kernel<true, float, float>(as, heur, w2)
-             : st == KFPOS_STORE_MIXED ? toa6_kernel<true, double, float>(as, heur, w2)
-                                       : toa6_kernel<true, double, double>(as, heur, w2);
+        if (h->full) return kfpos_k::toa6_full_kernel(st, as, heur);
+        /* more wavefronts than SIMDs: the 256-register build of the plain kernel */
+        return kfpos_k::toa6_sym_kernel(st, as, heur, toa6_two_waves(h));
     }
-    return st == KFPOS_STORE_F32 ? imu9_kernel<float, float>(as, !imu_only)
-         : st == KFPOS_STORE_MIXED ? imu9_kernel<double, float>(as, !imu_only) : imu9_kernel<double, double>(as, !imu_only);
+    return kfpos_k::imu9_kernel(st, as, !imu_only);
 }
 
 int launch_step(kfpos_handle *h, const KArgs &a, hipStream_t s) {
@@ -1224,9 +185,7 @@ int stage_in(kfpos_handle *h, void *dst, const void *src, int C, size_t esz) {
     const int rc = stage_region(h, T * C * esz, &rows);
     if (rc) return rc;
     HIPCHK(hipMemcpy(rows, src, T * C * esz, hipMemcpyHostToDevice));
-    const int blocks = (int)((T + 255) / 256);
-    if (esz == 4) hipLaunchKernelGGL(k_rows_to_cols<uint32_t>, dim3(blocks), dim3(256), 0, 0, (const uint32_t *)rows, (uint32_t *)dst, (int)T, C);
-    else hipLaunchKernelGGL(k_rows_to_cols<uint64_t>, dim3(blocks), dim3(256), 0, 0, (const uint64_t *)rows, (uint64_t *)dst, (int)T, C);
+    kfpos_k::launch_rows_to_cols(esz, nullptr, rows, dst, (int)T, C);
     HIPCHK(hipGetLastError());
     return KFPOS_OK;
 }
@@ -1240,8 +199,7 @@ int stage_out(kfpos_handle *h, double *dst, const double *dsrc, int C) {
     void *rows = nullptr;
     const int rc = stage_region(h, T * C * sizeof(double), &rows);
     if (rc) return rc;
-    const int blocks = (int)((T + 255) / 256);
-    hipLaunchKernelGGL(k_cols_to_rows<uint64_t>, dim3(blocks), dim3(256), 0, 0, (const uint64_t *)dsrc, (uint64_t *)rows, (int)T, C);
+    kfpos_k::launch_cols_to_rows(nullptr, dsrc, (double *)rows, (int)T, C);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpy(dst, rows, T * C * sizeof(double), hipMemcpyDeviceToHost));
     return KFPOS_OK;
@@ -1754,25 +712,7 @@ static int launch_pose(kfpos_handle *h, double dt_ahead, const double *dt_each, 
     a.cov = cov3x3;
     a.vel = vel;
     a.status = status;
-    const int blocks = (a.T + WAVE - 1) / WAVE;
-    const bool f32 = h->cfg.storage == KFPOS_STORE_F32;
-    hipStream_t s = (hipStream_t)stream;
-    if (h->cfg.model == KFPOS_MODEL_PLANAR) {
-        if (f32) hipLaunchKernelGGL((k_get_pose<8, true, float>), dim3(blocks), dim3(WAVE), 0, s, a);
-        else hipLaunchKernelGGL((k_get_pose<8, true, double>), dim3(blocks), dim3(WAVE), 0, s, a);
-    } else if (h->cfg.model == KFPOS_MODEL_ML) {
-        if (f32) hipLaunchKernelGGL((k_get_pose<3, true, float>), dim3(blocks), dim3(WAVE), 0, s, a);
-        else hipLaunchKernelGGL((k_get_pose<3, true, double>), dim3(blocks), dim3(WAVE), 0, s, a);
-    } else if (h->cfg.model == KFPOS_MODEL_TOA_IMU) {
-        if (f32) hipLaunchKernelGGL((k_get_pose<9, true, float>), dim3(blocks), dim3(WAVE), 0, s, a);
-        else hipLaunchKernelGGL((k_get_pose<9, true, double>), dim3(blocks), dim3(WAVE), 0, s, a);
-    } else if (h->full) {
-        if (f32) hipLaunchKernelGGL((k_get_pose<6, false, float>), dim3(blocks), dim3(WAVE), 0, s, a);
-        else hipLaunchKernelGGL((k_get_pose<6, false, double>), dim3(blocks), dim3(WAVE), 0, s, a);
-    } else {
-        if (f32) hipLaunchKernelGGL((k_get_pose<6, true, float>), dim3(blocks), dim3(WAVE), 0, s, a);
-        else hipLaunchKernelGGL((k_get_pose<6, true, double>), dim3(blocks), dim3(WAVE), 0, s, a);
-    }
+    kfpos_k::launch_get_pose(h->cfg.model, h->full != 0, h->cfg.storage, (a.T + WAVE - 1) / WAVE, (hipStream_t)stream, a);
     HIPCHK(hipGetLastError());
     return KFPOS_OK;
 }

@@ -1,6 +1,6 @@
 /*
  * kfpos_internal.h -- what the translation units of libkfpos_hip.so share and the ABI does not show: the handle.
- * (kfpos_hip.hip: kernels + filter entry points; kfpos_comm.hip: the RCCL pose gather.)
+ * (kfpos_k_*.hip: the kernels; kfpos_hip.hip: host side and filter entry points; kfpos_comm.hip: the RCCL pose gather.)
  */
 #ifndef KFPOS_INTERNAL_H
 #define KFPOS_INTERNAL_H
