@@ -62,9 +62,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # 1.6e-6 m RMS from the CPU reference over 100 steps (tests/test_gpu_parity.py), above the 1e-6 m bar, so the measured
 # configuration keeps it in f64 (KFPOS_STORE_MIXED: measurements stay f32 / int32). The kernel is VALU-bound, so this
 # does not change its duration; DESIGN.md "storage precision".
-_STORAGES = {"mixed": capi.STORE_MIXED, "f64": capi.STORE_F64, "f32": capi.STORE_F32}
-if hasattr(capi, "STORE_P48"):
-    _STORAGES["p48"] = capi.STORE_P48
+_STORAGES = {"mixed": capi.STORE_MIXED, "f64": capi.STORE_F64, "f32": capi.STORE_F32, "p48": capi.STORE_P48}
 STORAGE_C3_NAME = os.environ.get("KFPOS_BENCH_STORAGE", "mixed")
 STORAGE_C3 = _STORAGES[STORAGE_C3_NAME]
 _C3_TEXT = {
@@ -78,7 +76,9 @@ _C3_TEXT = {
 }[STORAGE_C3_NAME]
 CONFIGS = {
     "c3": dict(model=capi.MODEL_TOA_IMU, storage=STORAGE_C3, bytes=544, scaling="weak", tags=65536,
-               kernel="k_step_imu9<double,float,8,true>", dtype=_C3_TEXT[0],
+               kernel={"mixed": "k_step_imu9<double,float,8,true>", "f64": "k_step_imu9<double,double,8,true>",
+                       "f32": "k_step_imu9<float,float,8,true>", "p48": "k_step_imu9<p48,float,8,true>"}[STORAGE_C3_NAME],
+               dtype=_C3_TEXT[0],
                workload="BASELINE configs[2]: 65536 tags x 8 anchors per GPU, UWB+IMU fused 9-state IEKF "
                         "(kfpos_toa_imu path), fp64 arithmetic, " + _C3_TEXT[1]),
     "c4": dict(model=capi.MODEL_TOA, storage=capi.STORE_F64, bytes=560, scaling="strong", tags=1048576,

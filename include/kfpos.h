@@ -54,6 +54,9 @@ extern "C" {
 #define KFPOS_STORE_F64   0 /* covariance double, measurements (kfpos_real) double */
 #define KFPOS_STORE_F32   1 /* covariance float,  measurements (kfpos_real) float */
 #define KFPOS_STORE_MIXED 2 /* covariance double, measurements (kfpos_real) float: exact filter state, compact inputs */
+#define KFPOS_STORE_P48   3 /* covariance as the upper 48 bits of the double (6 bytes per entry: 36 mantissa bits, rounded to
+                               nearest even), measurements float: the compact mode that keeps the 9-state filter inside the
+                               1e-6 m bar (5e-10 m on the BASELINE trace; F32's 24 bits give 1.6e-6 m) */
 
 #define KFPOS_MAX_ANCHORS 64 /* MAX_NUM_ANCS, Posgenerator.h:74 */
 

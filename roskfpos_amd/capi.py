@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("KFPOS_LIB_PATH") or os.path.join(_DIR, "csrc", "libkf
 MODEL_TOA, MODEL_TOA_IMU, MODEL_ML, MODEL_PLANAR = 0, 1, 2, 3
 SENSOR_PX4FLOW, SENSOR_IMU, SENSOR_MAG, SENSOR_COMPASS = 1, 2, 3, 4
 _SENSOR_WIDTH = {1: 5, 2: 24, 3: 3, 4: 1}
-STORE_F64, STORE_F32, STORE_MIXED = 0, 1, 2
+STORE_F64, STORE_F32, STORE_MIXED, STORE_P48 = 0, 1, 2, 3
 ML_NORMAL, ML_IGNORE_N, ML_BEST = 0, 1, 2
 MAX_ANCHORS = 64
 ST_UPDATE_SKIPPED, ST_ML_FALLBACK, ST_FEW_RANGES, ST_ML_INIT, ST_NOT_STARTED, ST_NONFINITE = 1, 2, 4, 8, 16, 32

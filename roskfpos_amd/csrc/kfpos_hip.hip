@@ -315,7 +315,8 @@ int kfpos_create(const kfpos_config *cfg, kfpos_handle **out) {
     if (cfg->model != KFPOS_MODEL_TOA && cfg->model != KFPOS_MODEL_TOA_IMU && cfg->model != KFPOS_MODEL_ML &&
         cfg->model != KFPOS_MODEL_PLANAR)
         return bad("kfpos_config.model is not one of KFPOS_MODEL_*");
-    if (cfg->storage != KFPOS_STORE_F64 && cfg->storage != KFPOS_STORE_F32 && cfg->storage != KFPOS_STORE_MIXED)
+    if (cfg->storage != KFPOS_STORE_F64 && cfg->storage != KFPOS_STORE_F32 && cfg->storage != KFPOS_STORE_MIXED &&
+        cfg->storage != KFPOS_STORE_P48)
         return bad("kfpos_config.storage is not one of KFPOS_STORE_*");
     if (cfg->n_tags < 1) return bad("kfpos_config.n_tags must be >= 1");
     if (cfg->max_anchors < 1 || cfg->max_anchors > KFPOS_MAX_ANCHORS)
@@ -341,7 +342,7 @@ int kfpos_create(const kfpos_config *cfg, kfpos_handle **out) {
     h->n = cfg->model == KFPOS_MODEL_TOA_IMU ? 9 : (cfg->model == KFPOS_MODEL_ML ? 3 : (cfg->model == KFPOS_MODEL_PLANAR ? 8 : 6));
     h->full = (cfg->model == KFPOS_MODEL_TOA && !cfg->use_init_pos) ? 1 : 0;
     h->psz = h->full ? h->n * h->n : h->n * (h->n + 1) / 2;
-    h->rsz = cfg->storage == KFPOS_STORE_F32 ? 4 : 8;
+    h->rsz = cfg->storage == KFPOS_STORE_F32 ? 4 : (cfg->storage == KFPOS_STORE_P48 ? 6 : 8);
     h->msz = cfg->storage == KFPOS_STORE_F64 ? 8 : 4;
     h->A = 0;
     h->have_anchors = false;
@@ -1181,6 +1182,13 @@ int kfpos_get_state(kfpos_handle *h, double *x, double *P, uint32_t *flags) {
             for (int i = 0; i < n; ++i)
                 for (int j = 0; j < n; ++j) {
                     const size_t k = (size_t)pidx(h, i, j) * T + t;
+                    if (h->rsz == 6) { /* KFPOS_STORE_P48: [psz][T] uint32 (bits 63..32) | [psz][T] uint16 (bits 31..16) */
+                        const uint64_t hi = ((const uint32_t *)buf.data())[k];
+                        const uint64_t lo = ((const uint16_t *)(buf.data() + (size_t)h->psz * T * 4))[k];
+                        const uint64_t u = (hi << 32) | (lo << 16);
+                        std::memcpy(&P[(t * n + i) * n + j], &u, 8);
+                        continue;
+                    }
                     P[(t * n + i) * n + j] = h->rsz == 4 ? (double)((const float *)buf.data())[k]
                                                           : ((const double *)buf.data())[k];
                 }
@@ -1226,7 +1234,13 @@ int kfpos_set_state(kfpos_handle *h, const double *x, const double *P, const uin
                 for (int j = h->full ? 0 : i; j < n; ++j) {
                     const size_t k = (size_t)pidx(h, i, j) * T + t;
                     const double v = P[(t * n + i) * n + j];
-                    if (h->rsz == 4) ((float *)buf.data())[k] = (float)v;
+                    if (h->rsz == 6) { /* round to nearest even on the upper 48 bits, as the kernels do (round48) */
+                        uint64_t u;
+                        std::memcpy(&u, &v, 8);
+                        u = (u + 0x7FFFull + ((u >> 16) & 1ull)) & ~0xFFFFull;
+                        ((uint32_t *)buf.data())[k] = (uint32_t)(u >> 32);
+                        ((uint16_t *)(buf.data() + (size_t)h->psz * T * 4))[k] = (uint16_t)(u >> 16);
+                    } else if (h->rsz == 4) ((float *)buf.data())[k] = (float)v;
                     else ((double *)buf.data())[k] = v;
                 }
         HIPCHK(hipMemcpy(h->d_P, buf.data(), buf.size(), hipMemcpyHostToDevice));

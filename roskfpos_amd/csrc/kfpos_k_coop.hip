@@ -40,7 +40,7 @@ __global__ __launch_bounds__(WAVE) void k_step_toa6_coop(const KArgs a) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) tg.pos[k] = (a.pos + k * T)[t32];
 #pragma unroll
-    for (int k = 0; k < 21; ++k) tg.P.a[k] = ldrow<REAL>(a.P, k, T, t32);
+    for (int k = 0; k < 21; ++k) tg.P.a[k] = ldcov<REAL>(a.P, k, 21, T, t32);
     int32_t mm = 0;
     MREAL ee = (MREAL)1;
     if (has_anchor) {
@@ -62,10 +62,10 @@ __global__ __launch_bounds__(WAVE) void k_step_toa6_coop(const KArgs a) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) (a.traj + ((size_t)e * 3 + k) * T)[t32] = tg.pos[k];
         }
-        if constexpr (sizeof(REAL) == 4) {
+        if constexpr (cov_is_rounded<REAL>()) {
             if (e + 1 < a.n_steps) {
 #pragma unroll
-                for (int k = 0; k < 21; ++k) tg.P.a[k] = (double)(float)tg.P.a[k];
+                for (int k = 0; k < 21; ++k) tg.P.a[k] = round_cov<REAL>(tg.P.a[k]);
             }
         }
     }
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(WAVE) void k_step_toa6_coop(const KArgs a) {
     }
 #pragma unroll
     for (int k = 0; k < 21; ++k) {
-        strow<REAL>(a.P, k, T, t32, tg.P.a[k]);
+        stcov<REAL>(a.P, k, 21, T, t32, tg.P.a[k]);
         fin &= isfinite(tg.P.a[k]);
     }
     if (!fin) s |= ST_NONFINITE;
@@ -90,5 +90,6 @@ __global__ __launch_bounds__(WAVE) void k_step_toa6_coop(const KArgs a) {
 
 kfpos_k::step_kernel_t kfpos_k::toa6_coop_kernel(int st) {
     return st == KFPOS_STORE_F32 ? k_step_toa6_coop<float, float>
-         : st == KFPOS_STORE_MIXED ? k_step_toa6_coop<double, float> : k_step_toa6_coop<double, double>;
+         : st == KFPOS_STORE_MIXED ? k_step_toa6_coop<double, float>
+         : st == KFPOS_STORE_P48 ? k_step_toa6_coop<p48, float> : k_step_toa6_coop<double, double>;
 }

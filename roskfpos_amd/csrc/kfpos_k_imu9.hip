@@ -50,7 +50,7 @@ __global__ __launch_bounds__(WAVE) void k_step_imu9(const KArgs a) {
      * KFPOS_STORE_MIXED instantiation (the bench configuration); the other two (8-byte measurements: 22 more registers
      * per lane across the whole step; 4-byte covariance: its rounding code) do not have the registers for that (they
      * spill), so they fetch between two epochs instead */
-    constexpr bool AHEAD = sizeof(MREAL) == 4 && sizeof(REAL) == 8;
+    constexpr bool AHEAD = sizeof(MREAL) == 4 && !std::is_same<REAL, float>::value;
     const bool fresh_imu = a.mode != MODE_TOA;
     constexpr int NA = AS > 0 ? AS : 1;
     if (a.n_steps == 1 && a.dt && a.dt[t32] < 0.0) { /* no epoch / sample for this tag in this call */
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(WAVE) void k_step_imu9(const KArgs a) {
         cv[8] = ldrow<MREAL>(a.imu_cov, 5, T, t32);
     }
 #pragma unroll
-    for (int k = 0; k < 45; ++k) tg.P.a[k] = ldrow<REAL>(a.P, k, T, t32);
+    for (int k = 0; k < 45; ++k) tg.P.a[k] = ldcov<REAL>(a.P, k, 45, T, t32);
     if (fresh_imu) { /* the covariance of the first (usually: of every) epoch of this launch */
         imu.has = true;
 #pragma unroll
@@ -154,10 +154,10 @@ __global__ __launch_bounds__(WAVE) void k_step_imu9(const KArgs a) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) (a.traj + ((size_t)opaque_uniform(e) * 3 + k) * T)[t32] = tg.pos[k];
         }
-        if constexpr (sizeof(REAL) == 4) { /* what n single-epoch launches would have kept in HBM */
+        if constexpr (cov_is_rounded<REAL>()) { /* what n single-epoch launches would have kept in HBM */
             if (e + 1 < a.n_steps) {
 #pragma unroll
-                for (int k = 0; k < 45; ++k) tg.P.a[k] = (double)(float)tg.P.a[k];
+                for (int k = 0; k < 45; ++k) tg.P.a[k] = round_cov<REAL>(tg.P.a[k]);
             }
         }
     }
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(WAVE) void k_step_imu9(const KArgs a) {
     }
 #pragma unroll
     for (int k = 0; k < 45; ++k) {
-        strow<REAL>(a.P, k, T, t32, tg.P.a[k]);
+        stcov<REAL>(a.P, k, 45, T, t32, tg.P.a[k]);
         fin &= isfinite(tg.P.a[k]);
     }
     const bool waiting = !a.use_init_pos && isnan(tg.pos[0]);
@@ -194,6 +194,5 @@ static kfpos_k::step_kernel_t imu9_of(int as, bool ranging) {
     return k_step_imu9<REAL, MREAL, 0>;
 }
 kfpos_k::step_kernel_t kfpos_k::imu9_kernel(int st, int as, bool ranging) {
-    return st == KFPOS_STORE_F32 ? imu9_of<float, float>(as, ranging)
-         : st == KFPOS_STORE_MIXED ? imu9_of<double, float>(as, ranging) : imu9_of<double, double>(as, ranging);
+    return KFPOS_BY_STORAGE(st, imu9_of, as, ranging);
 }

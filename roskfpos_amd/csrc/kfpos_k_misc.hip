@@ -47,7 +47,7 @@ __global__ __launch_bounds__(WAVE) void k_step_ml(const KArgs a) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) (a.pos + k * T)[t32] = pos[k];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) strow<REAL>(a.P, k, T, t32, cov[k]);
+        for (int k = 0; k < 6; ++k) stcov<REAL>(a.P, k, 6, T, t32, cov[k]);
     }
     a.flags[t] |= FL_STARTED;
     if (a.status) a.status[t] = s;
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(WAVE) void k_step_planar(const KArgs a) {
         }
     }
 #pragma unroll
-    for (int k = 0; k < 36; ++k) tg.P.a[k] = ldrow<REAL>(a.P, k, T, t32);
+    for (int k = 0; k < 36; ++k) tg.P.a[k] = ldcov<REAL>(a.P, k, 36, T, t32);
 
     /* SENS: the predicted covariance is parked in LDS, [36][lane], behind the generic kernel's epoch scratch */
     const CovSpill8 park{lds + (AS < 0 ? 3 * (size_t)(-AS) * WAVE : ((AS == 0 && has_ranging) ? 3 * (size_t)a.A * WAVE : 0)) + lane, WAVE};
@@ -180,10 +180,10 @@ __global__ __launch_bounds__(WAVE) void k_step_planar(const KArgs a) {
             (a.traj + ((size_t)e * 3 + 1) * T)[t32] = tg.xy[1];
             (a.traj + ((size_t)e * 3 + 2) * T)[t32] = tg.z;
         }
-        if constexpr (sizeof(REAL) == 4) { /* what n single-epoch launches would have kept in HBM */
+        if constexpr (cov_is_rounded<REAL>()) { /* what n single-epoch launches would have kept in HBM */
             if (e + 1 < a.n_steps) {
 #pragma unroll
-                for (int k = 0; k < 36; ++k) tg.P.a[k] = (double)(float)tg.P.a[k];
+                for (int k = 0; k < 36; ++k) tg.P.a[k] = round_cov<REAL>(tg.P.a[k]);
             }
         }
     }
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(WAVE) void k_step_planar(const KArgs a) {
     (a.vel + 3 * T)[t32] = tg.om;
 #pragma unroll
     for (int k = 0; k < 36; ++k) {
-        strow<REAL>(a.P, k, T, t32, tg.P.a[k]);
+        stcov<REAL>(a.P, k, 36, T, t32, tg.P.a[k]);
         fin &= isfinite(tg.P.a[k]);
     }
     const bool waiting = !a.use_init_pos && isnan(tg.xy[0]);
@@ -235,8 +235,8 @@ __global__ __launch_bounds__(WAVE) void k_get_pose(const PoseArgs a) {
     } else if (MODEL == 3) { /* MLLocation::getPose: the estimate as it is */
 #pragma unroll
         for (int k = 0; k < 3; ++k) pos[k] = (a.pos_in + k * T)[t32];
-        const double c[6] = {ldrow<REAL>(a.P, 0, T, t32), ldrow<REAL>(a.P, 1, T, t32), ldrow<REAL>(a.P, 2, T, t32),
-                             ldrow<REAL>(a.P, 3, T, t32), ldrow<REAL>(a.P, 4, T, t32), ldrow<REAL>(a.P, 5, T, t32)};
+        const double c[6] = {ldcov<REAL>(a.P, 0, 6, T, t32), ldcov<REAL>(a.P, 1, 6, T, t32), ldcov<REAL>(a.P, 2, 6, T, t32),
+                             ldcov<REAL>(a.P, 3, 6, T, t32), ldcov<REAL>(a.P, 4, 6, T, t32), ldcov<REAL>(a.P, 5, 6, T, t32)};
         cov[0] = c[0]; cov[1] = c[1]; cov[2] = c[2]; cov[3] = c[1]; cov[4] = c[3]; cov[5] = c[4];
         cov[6] = c[2]; cov[7] = c[4]; cov[8] = c[5];
         if (a.full_P) {
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(WAVE) void k_get_pose(const PoseArgs a) {
         tg.ang = (a.vel_in + 2 * T)[t32];
         tg.om = (a.vel_in + 3 * T)[t32];
 #pragma unroll
-        for (int k = 0; k < 36; ++k) tg.P.a[k] = ldrow<REAL>(a.P, k, T, t32);
+        for (int k = 0; k < 36; ++k) tg.P.a[k] = ldcov<REAL>(a.P, k, 36, T, t32);
         double x8[8];
         Cov<8, true> Pp;
         pose8(tg, ahead, a.accel_noise, a.jolt, x8, Pp);
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(WAVE) void k_get_pose(const PoseArgs a) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) tg.pos[k] = (a.pos_in + k * T)[t32];
 #pragma unroll
-        for (int k = 0; k < Cov<6, SYMM>::SZ; ++k) tg.P.a[k] = ldrow<REAL>(a.P, k, T, t32);
+        for (int k = 0; k < Cov<6, SYMM>::SZ; ++k) tg.P.a[k] = ldcov<REAL>(a.P, k, Cov<6, SYMM>::SZ, T, t32);
         pose6<SYMM>(tg, ahead, a.accel_noise, pos, cov);
         if (a.full_P) { /* the whole predicted covariance, as getPose computes it (KalmanFilterTOA.cpp:467-468) */
             predict6(tg.P, ahead, a.accel_noise);
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(WAVE) void k_get_pose(const PoseArgs a) {
             tg.vel[k] = (a.vel_in + k * T)[t32];
         }
 #pragma unroll
-        for (int k = 0; k < 45; ++k) tg.P.a[k] = ldrow<REAL>(a.P, k, T, t32);
+        for (int k = 0; k < 45; ++k) tg.P.a[k] = ldcov<REAL>(a.P, k, 45, T, t32);
         pose9(tg, ahead, a.jolt, pos, vel, cov);
         if (a.full_P) { /* KalmanFilterTOAIMU.cpp:503-506 */
             predict9(tg.P, ahead, a.jolt);
@@ -346,8 +346,7 @@ static kfpos_k::step_kernel_t ml_of(int as) {
     return k_step_ml<REAL, MREAL, 0>;
 }
 kfpos_k::step_kernel_t kfpos_k::ml_kernel(int st, int as) {
-    return st == KFPOS_STORE_F32 ? ml_of<float, float>(as)
-         : st == KFPOS_STORE_MIXED ? ml_of<double, float>(as) : ml_of<double, double>(as);
+    return KFPOS_BY_STORAGE(st, ml_of, as);
 }
 
 /* With sensor rows the register-resident epoch of the 8-anchor specialisation no longer fits (measured: 212-244
@@ -361,33 +360,26 @@ static kfpos_k::step_kernel_t planar_of(int as) {
     }
     return k_step_planar<SENS, REAL, MREAL, 0>;
 }
-template <bool SENS>
-static kfpos_k::step_kernel_t planar_st(int st, int as) {
-    return st == KFPOS_STORE_F32 ? planar_of<SENS, float, float>(as)
-         : st == KFPOS_STORE_MIXED ? planar_of<SENS, double, float>(as) : planar_of<SENS, double, double>(as);
-}
+template <typename REAL, typename MREAL>
+static kfpos_k::step_kernel_t planar_sens(int as) { return planar_of<true, REAL, MREAL>(as); }
+template <typename REAL, typename MREAL>
+static kfpos_k::step_kernel_t planar_plain(int as) { return planar_of<false, REAL, MREAL>(as); }
 kfpos_k::step_kernel_t kfpos_k::planar_kernel(int st, bool sensors, int as) {
-    return sensors ? planar_st<true>(st, as) : planar_st<false>(st, as);
+    return sensors ? KFPOS_BY_STORAGE(st, planar_sens, as) : KFPOS_BY_STORAGE(st, planar_plain, as);
 }
 
+template <int MODEL, bool SYMM>
+static void pose_by_storage(int st, int blocks, hipStream_t s, const PoseArgs &a) {
+    if (st == KFPOS_STORE_F32) hipLaunchKernelGGL((k_get_pose<MODEL, SYMM, float>), dim3(blocks), dim3(WAVE), 0, s, a);
+    else if (st == KFPOS_STORE_P48) hipLaunchKernelGGL((k_get_pose<MODEL, SYMM, p48>), dim3(blocks), dim3(WAVE), 0, s, a);
+    else hipLaunchKernelGGL((k_get_pose<MODEL, SYMM, double>), dim3(blocks), dim3(WAVE), 0, s, a);
+}
 void kfpos_k::launch_get_pose(int model, bool full, int st, int blocks, hipStream_t s, const PoseArgs &a) {
-    const bool f32 = st == KFPOS_STORE_F32;
-    if (model == KFPOS_MODEL_PLANAR) {
-        if (f32) hipLaunchKernelGGL((k_get_pose<8, true, float>), dim3(blocks), dim3(WAVE), 0, s, a);
-        else hipLaunchKernelGGL((k_get_pose<8, true, double>), dim3(blocks), dim3(WAVE), 0, s, a);
-    } else if (model == KFPOS_MODEL_ML) {
-        if (f32) hipLaunchKernelGGL((k_get_pose<3, true, float>), dim3(blocks), dim3(WAVE), 0, s, a);
-        else hipLaunchKernelGGL((k_get_pose<3, true, double>), dim3(blocks), dim3(WAVE), 0, s, a);
-    } else if (model == KFPOS_MODEL_TOA_IMU) {
-        if (f32) hipLaunchKernelGGL((k_get_pose<9, true, float>), dim3(blocks), dim3(WAVE), 0, s, a);
-        else hipLaunchKernelGGL((k_get_pose<9, true, double>), dim3(blocks), dim3(WAVE), 0, s, a);
-    } else if (full) {
-        if (f32) hipLaunchKernelGGL((k_get_pose<6, false, float>), dim3(blocks), dim3(WAVE), 0, s, a);
-        else hipLaunchKernelGGL((k_get_pose<6, false, double>), dim3(blocks), dim3(WAVE), 0, s, a);
-    } else {
-        if (f32) hipLaunchKernelGGL((k_get_pose<6, true, float>), dim3(blocks), dim3(WAVE), 0, s, a);
-        else hipLaunchKernelGGL((k_get_pose<6, true, double>), dim3(blocks), dim3(WAVE), 0, s, a);
-    }
+    if (model == KFPOS_MODEL_PLANAR) pose_by_storage<8, true>(st, blocks, s, a);
+    else if (model == KFPOS_MODEL_ML) pose_by_storage<3, true>(st, blocks, s, a);
+    else if (model == KFPOS_MODEL_TOA_IMU) pose_by_storage<9, true>(st, blocks, s, a);
+    else if (full) pose_by_storage<6, false>(st, blocks, s, a);
+    else pose_by_storage<6, true>(st, blocks, s, a);
 }
 
 void kfpos_k::launch_rows_to_cols(size_t esz, hipStream_t s, const void *src, void *dst, int T, int C) {

@@ -9,8 +9,8 @@ namespace {
 
 } // namespace
 
+template <typename REAL, typename MREAL>
+static kfpos_k::step_kernel_t toa6_full(int as, int heur) { return toa6_kernel<false, REAL, MREAL>(as, heur); }
 kfpos_k::step_kernel_t kfpos_k::toa6_full_kernel(int st, int as, int heur) {
-    return st == KFPOS_STORE_F32 ? toa6_kernel<false, float, float>(as, heur)
-         : st == KFPOS_STORE_MIXED ? toa6_kernel<false, double, float>(as, heur)
-                                   : toa6_kernel<false, double, double>(as, heur);
+    return KFPOS_BY_STORAGE(st, toa6_full, as, heur);
 }

@@ -9,8 +9,8 @@ namespace {
 
 } // namespace
 
+template <typename REAL, typename MREAL>
+static kfpos_k::step_kernel_t toa6_sym(int as, int heur, bool two_waves) { return toa6_kernel<true, REAL, MREAL>(as, heur, two_waves); }
 kfpos_k::step_kernel_t kfpos_k::toa6_sym_kernel(int st, int as, int heur, bool two_waves) {
-    return st == KFPOS_STORE_F32 ? toa6_kernel<true, float, float>(as, heur, two_waves)
-         : st == KFPOS_STORE_MIXED ? toa6_kernel<true, double, float>(as, heur, two_waves)
-                                   : toa6_kernel<true, double, double>(as, heur, two_waves);
+    return KFPOS_BY_STORAGE(st, toa6_sym, as, heur, two_waves);
 }

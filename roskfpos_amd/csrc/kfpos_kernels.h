@@ -34,6 +34,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <type_traits>
 
 #define KFPOS_HD __host__ __device__
 #include "kfpos_core.h"
@@ -141,6 +142,56 @@ template <typename REAL>
 __device__ inline void strow(void *p, size_t row, size_t T, uint32_t t, double v) {
     (((REAL *)p) + row * T)[t] = (REAL)v;
 }
+
+/* ---- the covariance in HBM: [entries][tag] of double / float, or KFPOS_STORE_P48 ----
+ * P48: the upper 48 bits of the double, rounded to nearest even -- sign, exponent and 36 mantissa bits (1.5e-11
+ * relative), 6 bytes per entry. Two planes so that both stay coalesced: [entries][T] uint32 (bits 63..32) followed by
+ * [entries][T] uint16 (bits 31..16); a load is two loads and a shift-or, a store an integer add, a mask and two stores.
+ * (The 9-state filter amplifies a 24-bit covariance to 1.6e-6 m over 100 epochs of the BASELINE trace, above the 1e-6 m
+ * bar; at 36 bits it stays at 5e-10 m: profiles/r02v_covariance_encoding_study.json.) */
+struct p48 {};
+template <typename REAL>
+constexpr bool cov_is_rounded() { return !std::is_same<REAL, double>::value; }
+__device__ inline double round48(double v) {
+    unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    u = (u + 0x7FFFull + ((u >> 16) & 1ull)) & ~0xFFFFull;
+    /* (a NaN keeps its quiet bit, which sits in the upper 48: it stays a NaN; +-inf stays +-inf) */
+    return __longlong_as_double((long long)u);
+}
+/* what the storage type keeps of a value: applied between the epochs of a multi-epoch launch, so that it computes what
+ * as many single-epoch launches would */
+template <typename REAL>
+__device__ inline double round_cov(double v) {
+    if constexpr (std::is_same<REAL, p48>::value) return round48(v);
+    else return (double)(REAL)v;
+}
+template <typename REAL>
+__device__ inline double ldcov(const void *p, size_t row, size_t rows, size_t T, uint32_t t) {
+    if constexpr (std::is_same<REAL, p48>::value) {
+        const uint32_t hi = (((const uint32_t *)p) + row * T)[t];
+        const uint32_t lo = (((const uint16_t *)(((const uint32_t *)p) + rows * T)) + row * T)[t];
+        return __longlong_as_double((long long)(((unsigned long long)hi << 32) | ((unsigned long long)lo << 16)));
+    } else {
+        (void)rows;
+        return (double)(((const REAL *)p) + row * T)[t];
+    }
+}
+template <typename REAL>
+__device__ inline void stcov(void *p, size_t row, size_t rows, size_t T, uint32_t t, double v) {
+    if constexpr (std::is_same<REAL, p48>::value) {
+        const unsigned long long u = (unsigned long long)__double_as_longlong(round48(v));
+        (((uint32_t *)p) + row * T)[t] = (uint32_t)(u >> 32);
+        (((uint16_t *)(((uint32_t *)p) + rows * T)) + row * T)[t] = (uint16_t)(u >> 16);
+    } else {
+        (void)rows;
+        (((REAL *)p) + row * T)[t] = (REAL)v;
+    }
+}
+/* one kernel per storage mode: F<covariance type, measurement type>(args) */
+#define KFPOS_BY_STORAGE(st, F, ...)                                                                          \
+    ((st) == KFPOS_STORE_F32 ? F<float, float>(__VA_ARGS__)                                                   \
+     : (st) == KFPOS_STORE_MIXED ? F<double, float>(__VA_ARGS__)                                              \
+     : (st) == KFPOS_STORE_P48 ? F<p48, float>(__VA_ARGS__) : F<double, double>(__VA_ARGS__))
 
 template <class P>
 __device__ inline P make_params_of(const KArgs &a) {

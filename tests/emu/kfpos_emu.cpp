@@ -332,8 +332,10 @@ void kfe_round_storage(kfe_bank *b, int what) {
                         }
         } else if (b->full) {
             if (what & 1) for (double &v : b->t6f[t].P.a) v = (double)(float)v;
+            if (what & 8) for (double &v : b->t6f[t].P.a) v = enc_f48(v);
         } else {
             if (what & 1) for (double &v : b->t6s[t].P.a) v = (double)(float)v;
+            if (what & 8) for (double &v : b->t6s[t].P.a) v = enc_f48(v);
         }
     }
 }

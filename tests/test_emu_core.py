@@ -58,3 +58,32 @@ def test_iteration_counts_are_in_the_surveyed_range():
     gain = (st >> 8) & 0xFF
     ml = (st >> 16) & 0xFF
     assert 1.5 < gain[10:].mean() < 3.5 and 1.5 < ml[10:].mean() < 4.5
+
+
+@pytest.mark.parametrize("model,bar", [(1, 5e-9), (0, 1e-10)])
+def test_p48_covariance_storage_keeps_the_bar_on_the_baseline_trace(model, bar):
+    """KFPOS_STORE_P48 (the covariance kept as the upper 48 bits of the double between epochs) on the BASELINE-style
+    trace, kernel body on the host: the 9-state filter, which turns a 24-bit covariance into 1.6e-6 m, stays below
+    5e-9 m RMS (tests/cov_encoding_study.py: 5.5e-10 m at 2 048 tags). The GPU legs are in test_gpu_parity.py."""
+    import ctypes as C
+    from cases import Case
+    from impls import emu_lib, EmuStaticImpl
+    from roskfpos_amd.synth import Workload
+    T, S = 256, 100
+    case = Case("baseline", model, 8, T=T, S=S)
+    w = Workload(T, 8)
+    err, cov = w.err_est(np.float32).astype(np.float64), w.accel_cov(np.float32).astype(np.float64)
+    lib = emu_lib()
+    lib.kfe_round_storage.argtypes = [C.c_void_p, C.c_int]
+    orc, emu = OracleImpl(case, w, w.init_positions()), EmuStaticImpl(case, w, w.init_positions())
+    sq = 0.0
+    for s in range(S):
+        a = w.accel(s, np.float32).astype(np.float64)
+        for f in (orc, emu):
+            if model == 1:
+                f.fused(w.ranges_mm(s), err, a, cov, w.dt_of(s))
+            else:
+                f.step_toa(w.ranges_mm(s), err, w.dt_of(s))
+        lib.kfe_round_storage(emu.h, 8)
+        sq += ((emu.positions() - orc.positions()) ** 2).sum()
+    assert np.sqrt(sq / (T * S)) <= bar

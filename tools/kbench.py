@@ -26,6 +26,10 @@ CONFIGS = {
     "c4shard": (0, 131072, 8, capi.STORE_F64, 0, False, 560),
     "c3": (1, 65536, 8, capi.STORE_MIXED, 0, False, 544),
     "c3_f32": (1, 65536, 8, capi.STORE_F32, 0, False, 544),
+    # BASELINE configs[2] / [4] as worded ("fp32" = compact storage) in the compact mode that meets the 1e-6 m bar:
+    # 6-byte covariance entries (KFPOS_STORE_P48), f32 measurements
+    "c3_p48": (1, 65536, 8, capi.STORE_P48, 0, False, 544),
+    "c5_p48": (0, 262144, 16, capi.STORE_P48, 2, False, 344),
     "c5": (0, 262144, 16, capi.STORE_F32, 2, False, 344),
     "iw8": (0, 65536, 8, capi.STORE_F64, 0, True, 560),
     # small plain 6-state banks: where the 8-lanes-per-tag kernel (k_step_toa6_coop, KFPOS_NO_COOP=1 disables) pays off
