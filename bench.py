@@ -58,12 +58,16 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 #       accel(3) + covariance(9) f32:                          (9+45)*4*2 + 8*4*2 + (3+9)*4 = 544 B
 #   c4 / 6-state f64: x(6) + packed P(21) f64 in and out, 8 ranges + 8 errorEstimations at 8 B:
 #                                                              (6+21)*8*2 + 8*8*2           = 560 B
-# Covariance storage of c3: BASELINE configs[2] says fp32, but with a 24-bit covariance the 9-state filter sits at
-# 1.6e-6 m RMS from the CPU reference over 100 steps (tests/test_gpu_parity.py), above the 1e-6 m bar, so the measured
-# configuration keeps it in f64 (KFPOS_STORE_MIXED: measurements stay f32 / int32). The kernel is VALU-bound, so this
-# does not change its duration; DESIGN.md "storage precision".
+# Covariance storage of c3: BASELINE configs[2] says fp32, i.e. compact storage. With a 24-bit covariance
+# (KFPOS_STORE_F32) the 9-state filter sits at 1.6e-6 m RMS from the CPU reference over 100 steps
+# (tests/test_gpu_parity.py), above the 1e-6 m bar; with the covariance kept as the upper 48 bits of the double
+# (KFPOS_STORE_P48: 6 bytes per entry, measurements f32 / int32) it sits at 5e-10 m, and the kernel is as fast as with
+# an 8-byte covariance (same box, alternating: 37.6-37.7 us per epoch against 38.0-38.3,
+# profiles/r03a_kbench_p48_vs_mixed_same_box.jsonl) -- so P48 is what is measured. KFPOS_BENCH_STORAGE=mixed|f64|f32
+# selects the others. roofline.achieved uses SURVEY 8d's 544 B either way (P48 moves 54*6*2 + 112 = 760 B per tag-step
+# when every epoch is its own launch, MIXED 976 B).
 _STORAGES = {"mixed": capi.STORE_MIXED, "f64": capi.STORE_F64, "f32": capi.STORE_F32, "p48": capi.STORE_P48}
-STORAGE_C3_NAME = os.environ.get("KFPOS_BENCH_STORAGE", "mixed")
+STORAGE_C3_NAME = os.environ.get("KFPOS_BENCH_STORAGE", "p48")
 STORAGE_C3 = _STORAGES[STORAGE_C3_NAME]
 _C3_TEXT = {
     "mixed": ("f64 arithmetic; f64 state and covariance, f32/int32 measurements in HBM (KFPOS_STORE_MIXED)",
