@@ -185,6 +185,15 @@ KFPOS_FN bool rel_change_below(double cost, double c, double tol) {
     return lhs / cost < tol;
 }
 
+/* The Gauss-Newton loop's test  fabs(cost - newCost) / cost > tol  (MLLocation.cpp:168; :79 for the 2-D solver), the same
+ * way: every solve of every filter runs it once per pass. */
+KFPOS_FN bool rel_change_above(double cost, double c, double tol) {
+    const double lhs = fabs(cost - c), rhs = tol * cost;
+    const bool clear = cost > 0.0 && fabs(lhs - rhs) > 1e-13 * rhs; /* false for NaN and for cost <= 0 or inf */
+    if (KFPOS_WAVE_ALL(clear)) return lhs > rhs;
+    return lhs / cost > tol;
+}
+
 /* std::max as the reference uses it: (a < b) ? b : a (matters for NaN) */
 KFPOS_FN double stdmax(double a, double b) { return (a < b) ? b : a; }
 

@@ -48,7 +48,9 @@ KFPOS_FN void ml_sweep(const double p[3], const SC &sc, const Params &pr, uint64
         h4 += ty * dz;
         h5 += tz * dz;
     });
-    cw = group_sum(sc, cw_); sse = group_sum(sc, sse_);
+    /* 8 lanes per tag: the SSE is wanted of the LAST sweep only, so it stays a per-lane partial sum here and the caller
+     * combines it once, behind the loop (three DPP exchanges less in every pass) */
+    cw = group_sum(sc, cw_); sse = SC::COOP ? sse_ : group_sum(sc, sse_);
     g[0] = group_sum(sc, g0); g[1] = group_sum(sc, g1); g[2] = group_sum(sc, g2);
     /* (the diagonal term joins the partial sums before they are combined: no extra exchange in the 8-lanes-per-tag mode) */
     hs[0] = group_sum(sc, h0 + c0s); hs[1] = group_sum(sc, h1); hs[2] = group_sum(sc, h2);
@@ -131,7 +133,14 @@ KFPOS_FN int ml_estimate(double p[3], const SC &sc, const Params &pr, uint64_t d
             for (int k = 0; k < 6; ++k) first_out.hs[k] = hs[k];
         }
         if (iter > 0) newCost = cw;
-        if (!((fabs(cost - newCost) / cost > 1e-3) && (iter < 10000))) break; /* MLLocation.cpp:168 */
+        /* MLLocation.cpp:168. One tag per lane: the product form, no IEEE division per pass (-54 instructions per
+         * wave-epoch, 1-2.4 % of a 6-state step). 8 lanes per tag: that kernel is one dependent chain at 75 % issue
+         * occupancy, and there the vote and the extra branch of the product form cost more than the division they
+         * replace (same box: 4.38 -> 4.55 us per epoch, profiles/r03b_*): it keeps the quotient. */
+        bool go_on;
+        if constexpr (SC::COOP) go_on = fabs(cost - newCost) / cost > 1e-3;
+        else go_on = rel_change_above(cost, newCost, 1e-3);
+        if (!(go_on && (iter < 10000))) break;
         iter += 1;
         cost = newCost;
         const double idet = kf_rcp(sym3_cofactors(hs, c));
@@ -139,7 +148,7 @@ KFPOS_FN int ml_estimate(double p[3], const SC &sc, const Params &pr, uint64_t d
         p[1] -= (c[1] * g[0] + c[3] * g[1] + c[4] * g[2]) * idet;
         p[2] -= (c[2] * g[0] + c[4] * g[1] + c[5] * g[2]) * idet;
     }
-    sse_out = sse;
+    sse_out = group_sum(sc, sse); /* (identity unless 8 lanes share the tag: ml_sweep) */
     return iter;
 }
 

@@ -136,7 +136,7 @@ KFPOS_FN int ml2d_estimate(double p[2], double z, const SC &sc, const Params &pr
     ml2d_sweep(p, z, sc, pr, sse, g, hs);
     double cost = 1e20, newCost = sse;
     int iter = 0;
-    while ((fabs(cost - newCost) / cost > 1e-3) && (iter < 10000)) {
+    while (rel_change_above(cost, newCost, 1e-3) && (iter < 10000)) { /* MLLocation.cpp:79 */
         iter += 1;
         cost = newCost;
         const double idet = kf_rcp(hs[0] * hs[2] - hs[1] * hs[1]);
