@@ -355,17 +355,22 @@ def run(args, cfg, torch, dist, rank, local_rank, world, backend, device, n_dev,
             torch.cuda.synchronize()
 
     engines = set()
+    fallbacks = []
     gathers_made = {}
 
     def gather_for(mode, epochs_per_launch):
         """one PoseGather (= one communicator) per block shape, shared by every replay that needs it"""
         if world == 1 or mode == "none":
             return None
-        from roskfpos_amd.dist import PoseGather, shard_sizes
+        from roskfpos_amd.dist import make_pose_gather, shard_sizes
         rows = 3 * epochs_per_launch if mode == "trajectory" else 3
         if rows not in gathers_made:
-            gathers_made[rows] = PoseGather(T, device, rows=rows, sizes=shard_sizes(total, world))
+            # the library's RCCL communicator behind the C ABI when every rank has a GPU of its own -- created and
+            # checked with one predictable gather first; torch.distributed's collective if any rank fails that
+            gathers_made[rows] = make_pose_gather(T, device, rows=rows, sizes=shard_sizes(total, world))
             engines.add(gathers_made[rows].engine)
+            if gathers_made[rows].fallback_reason:
+                fallbacks.append(gathers_made[rows].fallback_reason)
         return gathers_made[rows]
 
     def measure(epochs_per_launch, gather_mode, tr=trace, bank=None):
@@ -496,6 +501,8 @@ def run(args, cfg, torch, dist, rank, local_rank, world, backend, device, n_dev,
                               "line's shape only -- nothing here is a measurement")
             out["roofline"] = None
             out["data"] = "none (dry run)"
+        if fallbacks:
+            out["config"]["pose_gather_fallback"] = fallbacks[0]
         if world > 1 and n_dev and world > n_dev:
             out["config"]["note"] = (f"{world} ranks on {n_dev} device(s): a rehearsal of the N > 1 code path, not a "
                                      "scaling measurement")

@@ -60,6 +60,37 @@ def default_engine(device) -> str:
     return "cabi" if (dist.is_initialized() and dist.get_world_size() > 1) else "torch"
 
 
+def make_pose_gather(t_local: int, device, rows: int = 3, sizes=None, engine: str = None):
+    """PoseGather with the engine default_engine() picks -- and, when that is the C ABI, a safety net for its first
+    contact with a machine: the communicator is created and checked with one predictable gather; if ANY rank fails
+    either step, every rank falls back to torch.distributed's collective (agreed through an all-reduce), and the
+    returned object says which engine it ended up with (.engine, .fallback_reason)."""
+    import torch
+    import torch.distributed as dist
+    want = engine or default_engine(device)
+    if want != "cabi" or not dist.is_initialized() or dist.get_world_size() == 1:
+        g = PoseGather(t_local, device, rows=rows, sizes=sizes, engine=want)
+        g.fallback_reason = None
+        return g
+    g, why = None, None
+    try:
+        g = PoseGather(t_local, device, rows=rows, sizes=sizes, engine="cabi")
+        if not g.self_check():
+            why = "the check gather returned something else than the pattern sent"
+    except Exception as e:  # noqa: BLE001 -- whatever went wrong, the other ranks have to hear about it
+        why = f"{type(e).__name__}: {e}"
+    flag = torch.tensor([0 if why else 1], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag[0]) == 1:
+        g.fallback_reason = None
+        return g
+    if g is not None:
+        g.close()
+    g = PoseGather(t_local, device, rows=rows, sizes=sizes, engine="torch")
+    g.fallback_reason = why or "another rank could not use the C-ABI gather"
+    return g
+
+
 class PoseGather:
     """All-gather of per-rank pose blocks [rows][t_local] -> every rank holds [rows][T_total], double-buffered.
 
@@ -128,6 +159,26 @@ class PoseGather:
         # tight [rows][t_local] blocks to fill when the caller has no contiguous source of its own
         self.local = [torch.zeros(self.rows, self.t_local, dtype=torch.float64, device=device) for _ in range(2)]
         self.out = [torch.zeros(self.rows, self.total, dtype=torch.float64, device=device) for _ in range(2)]
+
+    def self_check(self) -> bool:
+        """One gather of a pattern every rank can predict (global tag index + 1000 x row): True when this rank received
+        exactly that. Collective; leaves the double-buffer parity as it found it (two gathers)."""
+        torch = self.torch
+        lo = sum(self.sizes[:self.rank])
+        dev = self.local[0].device
+        cols = torch.arange(lo, lo + self.t_local, dtype=torch.float64, device=dev)
+        rows = torch.arange(self.rows, dtype=torch.float64, device=dev)[:, None] * 1000.0
+        want = torch.arange(self.total, dtype=torch.float64, device=dev)[None, :] + rows
+        ok = True
+        for _ in range(2):
+            buf = self.buffer()
+            buf[:, :self.t_local].copy_(cols[None, :] + rows)
+            got = self.gather()
+            self.wait()
+            if self.cuda:
+                torch.cuda.current_stream().synchronize()
+            ok = ok and bool(torch.equal(self.assemble(got), want))
+        return ok
 
     def close(self):
         if self.comm is not None:
@@ -257,7 +308,7 @@ class ShardedReplay:
                     raise ValueError("the PoseGather passed in was made for another block shape")
                 self.gather = gather
             else:
-                self.gather = PoseGather(self.T, device, rows=rows, sizes=self.sizes, engine=engine)
+                self.gather = make_pose_gather(self.T, device, rows=rows, sizes=self.sizes, engine=engine)
 
     def run(self, trace, s0: int, n: int, on_gathered=None):
         """Epochs [s0, s0 + n) of `trace` (dict: ranges, err, dts, traj, and accel / cov for the 9-state filter).

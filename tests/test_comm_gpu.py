@@ -119,6 +119,7 @@ def test_pose_gather_cabi_engine_equals_torch_engine(mode, epl):
                 blocks[first + k] = whole[3 * k:3 * k + 3].copy()
 
         rep.run(tr, 0, S, on_gathered=keep)
+        assert rep.gather.self_check()      # the predictable-pattern gather bench.py runs before trusting an engine
         got[engine] = blocks
         rep.gather.close()
         bank.close()

@@ -15,7 +15,7 @@ import torch.multiprocessing as mp
 
 from cases import Case
 from impls import EmuImpl
-from roskfpos_amd.dist import PoseGather, shard_range, shard_sizes
+from roskfpos_amd.dist import PoseGather, make_pose_gather, shard_range, shard_sizes
 from roskfpos_amd.synth import Workload
 
 T_TOTAL, A, S = 97, 8, 12  # 97: the two shards differ by one tag (49 + 48), the gather pads and trims
@@ -60,6 +60,11 @@ def _worker(rank, world, port, q):
     gt.buffer()[:, :hi - lo].copy_(torch.from_numpy(np.concatenate([p.T for p in poses])))
     block = gt.assemble(gt.gather()).clone().numpy()          # [3 S][T_TOTAL]
     gt.wait()
+    # the safety net of the C-ABI engine: asked for where it cannot work (CPU tensors), every rank must agree to fall
+    # back to torch.distributed's collective, say why, and still gather correctly
+    assert g.self_check() and gt.self_check()
+    gf = make_pose_gather(hi - lo, "cpu", rows=3, sizes=shard_sizes(T_TOTAL, world), engine="cabi")
+    assert gf.engine == "torch" and "HBM" in gf.fallback_reason and gf.self_check()
     if rank == 0:
         q.put((np.stack(gathered), block))
     dist.barrier()
