@@ -126,3 +126,26 @@ def test_pose_gather_cabi_engine_equals_torch_engine(mode, epl):
     assert sorted(got["torch"]) == sorted(got["cabi"]) and len(got["cabi"]) >= S // epl
     for s in got["torch"]:
         assert np.array_equal(got["torch"][s], got["cabi"][s])
+
+
+def test_cpp_node_shards_without_python(tmp_path):
+    """tools/shard_node.cpp: a C++ multi-tag node on the C ABI alone -- kfpos_comm_create_all, one handle per device,
+    kfpos_allgather_poses_multi once per epoch -- built with hipcc and run on the one device of this box. Its exit status
+    says whether every device received exactly the poses the shards' own getPose reports."""
+    if not has_gpu():
+        pytest.skip("no GPU")
+    import json
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "roskfpos_amd", "csrc")
+    exe = str(tmp_path / "shard_node")
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    subprocess.check_call([hipcc, "-O2", "-std=c++17", "-I", os.path.join(root, "include"), "-o", exe,
+                           os.path.join(root, "tools", "shard_node.cpp"), "-L", csrc, "-lkfpos_hip",
+                           "-Wl,-rpath," + csrc])
+    res = subprocess.run([exe, "1", "50001", "12"], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    d = json.loads(res.stdout.strip().splitlines()[-1])
+    assert d["devices"] == 1 and d["mismatches"] == 0 and d["rccl_version"] >= 20000
