@@ -2,7 +2,7 @@
 """Long-run parity: 2 048 tags x 2 000 epochs through the C ABI against the oracle (test infrastructure: it uses oracle/, hence it lives under tests/), both
 filters; prints RMS / max position difference and the fraction of differing status words every 250 epochs.
 
-    python tests/soak.py
+    python tests/soak.py [f64|mixed|f32|p48]      (covariance / measurement storage of the GPU bank; default f64)
 """
 import sys, os, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,18 +11,22 @@ from roskfpos_amd import capi
 from roskfpos_amd.synth import Workload
 import oracle_py
 T, S = 2048, 2000
+mode = sys.argv[1] if len(sys.argv) > 1 else "f64"
+storage = {"f64": capi.STORE_F64, "mixed": capi.STORE_MIXED, "f32": capi.STORE_F32, "p48": capi.STORE_P48}[mode]
+real = np.float64 if storage == capi.STORE_F64 else np.float32
+print(f"storage {mode}", flush=True)
 for model in (0, 1):
     w = Workload(T, 8)
-    b = capi.KfposBank(model, T, w.anchors, init_pos=w.init_positions())
+    b = capi.KfposBank(model, T, w.anchors, storage=storage, init_pos=w.init_positions())
     o = oracle_py.OracleBank(model, T, w.anchors, init_pos=w.init_positions(), n_threads=16)
-    err, cov = w.err_est(), w.accel_cov()
+    err, cov = w.err_est(real).astype(np.float64), w.accel_cov(real).astype(np.float64)
     worst = 0.0
     for s in range(S):
-        r, a, dt = w.ranges_mm(s), w.accel(s), w.dt_of(s)
+        r, a, dt = w.ranges_mm(s), w.accel(s, real).astype(np.float64), w.dt_of(s)
         if model == 1:
-            sb = b.step_toa_imu(r, err, a, cov, dt); o.step_imu(a, cov, 0.0); so = o.step_toa(r, err, dt)
+            sb = b.step_toa_imu(r, err.astype(real), a.astype(real), cov.astype(real), dt); o.step_imu(a, cov, 0.0); so = o.step_toa(r, err, dt)
         else:
-            sb = b.step_toa(r, err, dt); so = o.step_toa(r, err, dt)
+            sb = b.step_toa(r, err.astype(real), dt); so = o.step_toa(r, err, dt)
         if s % 250 == 249 or s == S - 1:
             xb = b.get_state()[0]; xo = o.get_state()[0]
             rms = float(np.sqrt(((xb[:, :3] - xo[:, :3]) ** 2).sum(1).mean()))

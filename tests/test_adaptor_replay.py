@@ -110,3 +110,30 @@ def test_replay_algorithm_ml_matches_oracle(tmp_path, variant, ignore_n, start):
     # the variants without a defined result in the reference are refused
     r = subprocess.run([REPLAY, "algorithm:=ALGORITHM_ML", "use2d:=1", trace], capture_output=True, text=True)
     assert r.returncode == 1 and "use2d" in r.stderr
+
+
+@pytest.mark.gpu
+def test_replay_algorithm_ml_variant_best_with_five_beacons(tmp_path):
+    """ALGORITHM_ML variant:=2 (ML_VARIANT_BEST, estimatePositionBestGroup) through the host MLLocation class: defined
+    for up to 5 beacons (MLLocation.cpp:377-381 runs past the end of its vector from 6 on); with 12 the node refuses."""
+    S, tag = 20, 3
+    w = Workload(8, 5)
+    trace = str(tmp_path / "trace.txt")
+    _write_trace(trace, w, S, tag, with_imu=False)
+    p0 = w.init_positions()[tag] + 0.3
+    args = [REPLAY, "algorithm:=ALGORITHM_ML", "useStartPosition:=1", "variant:=2", f"initPositionX:={p0[0]:.17g}",
+            f"initPositionY:={p0[1]:.17g}", f"initPositionZ:={p0[2]:.17g}"]
+    out = subprocess.run(args + [trace], capture_output=True, text=True, check=True).stdout
+    got = np.array([[float(v) for v in ln.split()[2:]] for ln in out.splitlines() if ln.startswith("P")])
+    assert got.shape == (S, 7) and np.all(got[:, 0] == 1)
+    orc = oracle_py.OracleBank(oracle_py.MODEL_ML, 1, w.anchors, init_pos=p0[None], ml_variant=2)
+    for s in range(S):
+        orc.step_toa(w.ranges_mm(s)[tag:tag + 1], w.err_est()[tag:tag + 1], 0.05)
+        pos, c, _, _ = orc.get_pose(0.0)
+        assert np.abs(got[s, 1:4] - pos[0]).max() < 1e-8
+        assert np.allclose(got[s, 4:], [c[0, 0, 0], c[0, 1, 1], c[0, 2, 2]], rtol=1e-6, atol=1e-12)
+    w12 = Workload(8, 12)
+    trace12 = str(tmp_path / "trace12.txt")
+    _write_trace(trace12, w12, 3, tag, with_imu=False)
+    r = subprocess.run(args + [trace12], capture_output=True, text=True)
+    assert r.returncode != 0 and "estimatePositionBestGroup" in r.stderr
