@@ -120,9 +120,18 @@ def launch_ranks(n: int, argv) -> int:
             out.write(text)
             out.flush()
 
+    import signal
     import threading
     pump = threading.Thread(target=relay, daemon=True)
     pump.start()
+
+    def pass_on(signum, _frame):  # whoever stops the launcher stops its ranks too (exactly the PIDs started above)
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        raise KeyboardInterrupt
+
+    signal.signal(signal.SIGTERM, pass_on)
     rc = 0
     try:
         pending = set(range(n))
