@@ -365,6 +365,7 @@ def run(args, cfg, torch, dist, rank, local_rank, world, backend, device, n_dev,
 
     engines = set()
     fallbacks = []
+    calibrations = {}
     gathers_made = {}
 
     def gather_for(mode, epochs_per_launch):
@@ -380,6 +381,8 @@ def run(args, cfg, torch, dist, rank, local_rank, world, backend, device, n_dev,
             engines.add(gathers_made[rows].engine)
             if gathers_made[rows].fallback_reason:
                 fallbacks.append(gathers_made[rows].fallback_reason)
+            if gathers_made[rows].calibration:
+                calibrations[f"{rows} rows"] = gathers_made[rows].calibration
         return gathers_made[rows]
 
     def measure(epochs_per_launch, gather_mode, tr=trace, bank=None):
@@ -512,6 +515,8 @@ def run(args, cfg, torch, dist, rank, local_rank, world, backend, device, n_dev,
             out["data"] = "none (dry run)"
         if fallbacks:
             out["config"]["pose_gather_fallback"] = fallbacks[0]
+        if calibrations:  # RCCL's all-gather against every rank sending straight to every other one, timed on this machine
+            out["config"]["pose_gather_algorithms"] = calibrations
         if world > 1 and n_dev and world > n_dev:
             out["config"]["note"] = (f"{world} ranks on {n_dev} device(s): a rehearsal of the N > 1 code path, not a "
                                      "scaling measurement")

@@ -372,6 +372,15 @@ int kfpos_allgather_poses(kfpos_handle *h, kfpos_comm *c, const double *pos_loca
 int kfpos_allgather_poses_multi(int32_t n, kfpos_handle *const *handles, kfpos_comm *const *comms,
                                 const double *const *pos_local, int32_t rows, double *const *pos_all,
                                 void *const *streams);
+/* How the blocks of a gather travel. COLLECTIVE: ncclAllGather, RCCL's own schedule. DIRECT: every rank sends its block
+ * to each other rank and receives theirs in one RCCL group (ncclSend / ncclRecv) -- on MI355X every pair of GPUs has its
+ * own xGMI link, so a rank's world-1 transfers run side by side, one hop each, where a ring passes every block through
+ * world-1 hops. Same result, same buffers; which is faster at a given size is for the machine to say (bench.py times
+ * both). All ranks must choose alike; default COLLECTIVE, or KFPOS_GATHER_ALGO=direct in the environment at creation. */
+#define KFPOS_GATHER_COLLECTIVE 0
+#define KFPOS_GATHER_DIRECT     1
+int kfpos_comm_set_algorithm(kfpos_comm *c, int32_t algorithm);
+int kfpos_comm_algorithm(const kfpos_comm *c);
 int kfpos_comm_wait(kfpos_comm *c, void *stream);
 int kfpos_comm_sync(kfpos_comm *c);
 /* The assembly step alone, for a caller that gathers with a collective of its own (torch.distributed, MPI):

@@ -38,8 +38,9 @@ EXPORTS = [
     "kfpos_shard_range", "kfpos_comm_unique_id", "kfpos_comm_create", "kfpos_comm_create_all", "kfpos_comm_destroy",
     "kfpos_comm_world", "kfpos_comm_rank", "kfpos_comm_set_total", "kfpos_allgather_poses",
     "kfpos_allgather_poses_multi", "kfpos_comm_wait", "kfpos_comm_sync", "kfpos_assemble_poses_dev",
-    "kfpos_comm_backend_version",
+    "kfpos_comm_backend_version", "kfpos_comm_set_algorithm", "kfpos_comm_algorithm",
 ]
+GATHER_COLLECTIVE, GATHER_DIRECT = 0, 1
 COMM_ID_BYTES = 128
 SLOT_TOA, SLOT_IMU, SLOT_TOA_IMU = 0, 1, 2
 SLOT_DT_PER_TAG, SLOT_REUSE_ERR, SLOT_REUSE_COV, SLOT_NO_POSE = 0x100, 0x200, 0x400, 0x800
@@ -149,6 +150,8 @@ def load():
     sig("kfpos_comm_sync", [vp])
     sig("kfpos_assemble_poses_dev", [i32, i32, i64, vp, vp, i32, vp])
     sig("kfpos_comm_backend_version", [])
+    sig("kfpos_comm_set_algorithm", [vp, i32])
+    sig("kfpos_comm_algorithm", [vp])
     L.kfpos_last_error.restype = C.c_char_p
     L.kfpos_strerror.restype = C.c_char_p
     sig("kfpos_strerror", [C.c_int])
@@ -469,6 +472,14 @@ class KfposComm:
         """pos_local [rows][t_local] (or the bank's current positions) -> pos_all [rows][total]; asynchronous."""
         _chk_lib(self.lib, self.lib.kfpos_allgather_poses(bank._h if bank is not None else None, self._c,
                                                           _ptr(pos_local), rows, _ptr(pos_all), _ptr(stream)))
+
+    def set_algorithm(self, algorithm: int):
+        """GATHER_COLLECTIVE (ncclAllGather) or GATHER_DIRECT (grouped ncclSend / ncclRecv to every peer)."""
+        _chk_lib(self.lib, self.lib.kfpos_comm_set_algorithm(self._c, algorithm))
+
+    @property
+    def algorithm(self) -> int:
+        return self.lib.kfpos_comm_algorithm(self._c)
 
     def wait(self, stream=None):
         _chk_lib(self.lib, self.lib.kfpos_comm_wait(self._c, _ptr(stream)))

@@ -19,6 +19,15 @@
  * is what protects scaling. pos_local may be overwritten as soon as the call returns (stream-ordered behind the pack);
  * pos_all is valid after kfpos_comm_wait() / kfpos_comm_sync().
  *
+ * How the blocks travel (kfpos_comm_set_algorithm; KFPOS_GATHER_ALGO=direct|collective at communicator creation):
+ *   collective  ncclAllGather: RCCL's own schedule (rings over the xGMI links)
+ *   direct      every rank SENDS its block to each of the other world-1 ranks and receives theirs, all in one RCCL
+ *               group (ncclSend / ncclRecv): on MI355X every pair of GPUs has its own xGMI link, so the world-1
+ *               transfers of a rank run side by side, one hop each -- 3 MB per link for a 131 072-tag shard -- where a
+ *               ring passes every block through world-1 hops. Which of the two is faster at a given size is a property
+ *               of the machine: bench.py times both before its timed region and says what it picked.
+ * Both fill the same staged [world][rows][t_pad] image, so everything around them is shared.
+ *
  * librccl is opened on first use (dlopen), not linked: a process that never shards -- the single-tag adaptor objects, a
  * one-GPU node -- does not map a 570 MB library, and a process that already has RCCL (PyTorch's copy has the same
  * soname) shares it.
@@ -57,6 +66,8 @@ struct Rccl {
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclCommAbort) CommAbort = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
@@ -91,6 +102,8 @@ Rccl &rccl() {
         r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
         r.CommAbort = (decltype(r.CommAbort))sym("ncclCommAbort");
         r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
+        r.Send = (decltype(r.Send))sym("ncclSend");
+        r.Recv = (decltype(r.Recv))sym("ncclRecv");
         r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
         r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
         r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
@@ -164,12 +177,15 @@ struct kfpos_comm {
     size_t cap_rows = 0; /* rows the buffers are sized for */
     unsigned long long calls = 0;
     int last = -1; /* buffer set of the last gather */
+    int algo = KFPOS_GATHER_COLLECTIVE; /* how the blocks travel: kfpos_comm_set_algorithm */
 };
 
 namespace {
 
 int comm_finish_init(kfpos_comm *c) {
     KfposDevScope dev(c->device);
+    const char *algo = getenv("KFPOS_GATHER_ALGO");
+    if (algo && std::strcmp(algo, "direct") == 0) c->algo = KFPOS_GATHER_DIRECT;
     HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
     for (int b = 0; b < 2; ++b) {
         HIPCHK(hipEventCreateWithFlags(&c->ready[b], hipEventDisableTiming));
@@ -233,6 +249,32 @@ int gather_front(kfpos_handle *h, kfpos_comm *c, const double *pos_local, int ro
     HIPCHK(hipStreamWaitEvent(c->side, c->ready[b], 0));
     plan = GatherPlan{c, b, rows, pos_all};
     return KFPOS_OK;
+}
+
+/* the exchange itself, enqueued on the side stream; inside an RCCL group when `grouped` (the caller opened it) */
+ncclResult_t exchange(const GatherPlan &p, bool grouped) {
+    kfpos_comm *c = p.c;
+    const size_t count = (size_t)p.rows * c->t_pad;
+    if (c->algo != KFPOS_GATHER_DIRECT)
+        return rccl().AllGather(c->send[p.b], c->staged[p.b], count, ncclDouble, c->nccl, c->side);
+    ncclResult_t first = ncclSuccess;
+    if (!grouped) first = rccl().GroupStart();
+    for (int peer = 0; peer < c->world && first == ncclSuccess; ++peer) {
+        if (peer == c->rank) continue;
+        first = rccl().Send(c->send[p.b], count, ncclDouble, peer, c->nccl, c->side);
+        if (first == ncclSuccess)
+            first = rccl().Recv(c->staged[p.b] + (size_t)peer * count, count, ncclDouble, peer, c->nccl, c->side);
+    }
+    if (!grouped) {
+        const ncclResult_t e = rccl().GroupEnd();
+        if (first == ncclSuccess) first = e;
+    }
+    /* this rank's own block does not travel */
+    if (first == ncclSuccess &&
+        hipMemcpyAsync(c->staged[p.b] + (size_t)c->rank * count, c->send[p.b], count * sizeof(double),
+                       hipMemcpyDeviceToDevice, c->side) != hipSuccess)
+        first = ncclUnhandledCudaError;
+    return first;
 }
 
 /* everything behind it, on the side stream */
@@ -377,6 +419,16 @@ int kfpos_comm_destroy(kfpos_comm *c) {
     return KFPOS_OK;
 }
 
+int kfpos_comm_set_algorithm(kfpos_comm *c, int32_t algorithm) {
+    g_err.clear();
+    if (!c || (algorithm != KFPOS_GATHER_COLLECTIVE && algorithm != KFPOS_GATHER_DIRECT)) return KFPOS_ERR_ARG;
+    KfposDevScope dev(c->device);
+    if (c->side) HIPCHK(hipStreamSynchronize(c->side)); /* between two gathers, never inside one */
+    c->algo = algorithm;
+    return KFPOS_OK;
+}
+int kfpos_comm_algorithm(const kfpos_comm *c) { return c ? c->algo : -1; }
+
 int kfpos_comm_world(const kfpos_comm *c) { return c ? c->world : 0; }
 int kfpos_comm_rank(const kfpos_comm *c) { return c ? c->rank : -1; }
 
@@ -412,7 +464,7 @@ int kfpos_allgather_poses(kfpos_handle *h, kfpos_comm *c, const double *pos_loca
     GatherPlan p;
     int rc = gather_front(h, c, pos_local, rows, pos_all, (hipStream_t)stream, p);
     if (rc) return rc;
-    NCCLCHK(rccl().AllGather(c->send[p.b], c->staged[p.b], (size_t)rows * c->t_pad, ncclDouble, c->nccl, c->side));
+    NCCLCHK(exchange(p, false));
     return gather_back(p);
 }
 
@@ -434,15 +486,13 @@ int kfpos_allgather_poses_multi(int32_t n, kfpos_handle *const *handles, kfpos_c
     NCCLCHK(rccl().GroupStart());
     ncclResult_t first = ncclSuccess;
     for (int i = 0; i < n; ++i) {
-        kfpos_comm *c = comms[i];
-        ncclResult_t r = rccl().AllGather(c->send[plans[i].b], c->staged[plans[i].b], (size_t)rows * c->t_pad, ncclDouble,
-                                          c->nccl, c->side);
+        const ncclResult_t r = exchange(plans[i], true);
         if (r != ncclSuccess && first == ncclSuccess) first = r;
     }
     ncclResult_t e = rccl().GroupEnd();
     if (first == ncclSuccess) first = e;
     if (first != ncclSuccess) {
-        g_err = std::string("ncclAllGather (group): ") + rccl().GetErrorString(first);
+        g_err = std::string("pose exchange (RCCL group): ") + rccl().GetErrorString(first);
         return KFPOS_ERR_COMM;
     }
     for (int i = 0; i < n; ++i) {

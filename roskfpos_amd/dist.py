@@ -71,6 +71,7 @@ def make_pose_gather(t_local: int, device, rows: int = 3, sizes=None, engine: st
     if want != "cabi" or not dist.is_initialized() or dist.get_world_size() == 1:
         g = PoseGather(t_local, device, rows=rows, sizes=sizes, engine=want)
         g.fallback_reason = None
+        g.calibration = None
         return g
     g, why = None, None
     try:
@@ -83,12 +84,56 @@ def make_pose_gather(t_local: int, device, rows: int = 3, sizes=None, engine: st
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if int(flag[0]) == 1:
         g.fallback_reason = None
+        g.calibration = _pick_algorithm(g, device)
         return g
     if g is not None:
         g.close()
     g = PoseGather(t_local, device, rows=rows, sizes=sizes, engine="torch")
     g.fallback_reason = why or "another rank could not use the C-ABI gather"
+    g.calibration = None
     return g
+
+
+def _pick_algorithm(g, device, reps: int = 6):
+    """Which way the blocks should travel on THIS machine at THIS block size: RCCL's all-gather, or every rank sending
+    its block straight to every other one (include/kfpos.h: KFPOS_GATHER_DIRECT; on MI355X each pair of GPUs has an xGMI
+    link of its own). Both are checked with the predictable pattern and timed -- `reps` back-to-back gathers, the
+    slowest rank counts -- and the faster one that passed stays selected. Every rank reaches the same verdict (the
+    numbers are all-reduced). KFPOS_GATHER_ALGO=direct|collective pins the choice instead."""
+    import time
+    import torch
+    import torch.distributed as dist
+    from . import capi
+    forced = os.environ.get("KFPOS_GATHER_ALGO")
+    if forced in ("direct", "collective"):
+        g.comm.set_algorithm(capi.GATHER_DIRECT if forced == "direct" else capi.GATHER_COLLECTIVE)
+        return {"picked": forced, "why": "KFPOS_GATHER_ALGO"}
+    out = {}
+    for name, algo in (("collective", capi.GATHER_COLLECTIVE), ("direct", capi.GATHER_DIRECT)):
+        ok, us = 1, float("inf")
+        try:
+            g.comm.set_algorithm(algo)
+            ok = 1 if g.self_check() else 0
+            if ok:
+                torch.cuda.synchronize()
+                dist.barrier()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    g.gather()
+                g.wait()
+                torch.cuda.synchronize()
+                us = (time.perf_counter() - t0) * 1e6 / reps
+        except Exception:  # noqa: BLE001
+            ok = 0
+        v = torch.tensor([float(ok), -us if ok else float("-inf")], dtype=torch.float64, device=device)
+        dist.all_reduce(v, op=dist.ReduceOp.MIN)   # ok on every rank; the slowest rank's time
+        out[name] = {"ok": bool(v[0] == 1.0), "us_per_gather": (-float(v[1])) if v[0] == 1.0 else None}
+    good = [n for n in out if out[n]["ok"]]
+    pick = min(good, key=lambda n: out[n]["us_per_gather"]) if good else "collective"
+    g.comm.set_algorithm(capi.GATHER_DIRECT if pick == "direct" else capi.GATHER_COLLECTIVE)
+    out["picked"] = pick
+    out["block_bytes_per_rank"] = g.rows * g.t_pad * 8
+    return out
 
 
 class PoseGather:

@@ -46,13 +46,20 @@ def test_world_one_communicator_gathers_handle_positions_and_trajectories():
     torch.cuda.synchronize()
     x, _, _ = bank.get_state()
     assert np.array_equal(out.cpu().numpy().T, x[:, :3])
-    # (2) a whole trajectory block, three gathers in flight before anything waits (the third waits for the first)
-    outs = [torch.zeros(3 * S, T, dtype=torch.float64, device=dev) for _ in range(3)]
-    for o in outs:
-        comm.allgather(o, pos_local=tr["traj"], rows=3 * S, stream=stream)
-    comm.sync()
-    for o in outs:
-        assert torch.equal(o.view(S, 3, T), tr["traj"])
+    # (2) a whole trajectory block, three gathers in flight before anything waits (the third waits for the first) -- with
+    # RCCL's all-gather and with the direct exchange (at world 1: this rank's own block, which never travels)
+    assert comm.algorithm == capi.GATHER_COLLECTIVE
+    for algo in (capi.GATHER_COLLECTIVE, capi.GATHER_DIRECT, capi.GATHER_COLLECTIVE):
+        comm.set_algorithm(algo)
+        assert comm.algorithm == algo
+        outs = [torch.zeros(3 * S, T, dtype=torch.float64, device=dev) for _ in range(3)]
+        for o in outs:
+            comm.allgather(o, pos_local=tr["traj"], rows=3 * S, stream=stream)
+        comm.sync()
+        for o in outs:
+            assert torch.equal(o.view(S, 3, T), tr["traj"])
+    with pytest.raises(capi.KfposError):
+        comm.set_algorithm(7)
     # (3) a handle that is not this communicator's shard is refused
     other = capi.KfposBank(capi.MODEL_TOA, T - 1, w.anchors, init_pos=np.zeros(3))
     with pytest.raises(capi.KfposError, match="disagree"):

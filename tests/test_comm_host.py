@@ -38,6 +38,7 @@ def test_comm_argument_errors_without_touching_rccl():
     assert lib.kfpos_comm_destroy(None) == 1 and lib.kfpos_comm_sync(None) == 1 and lib.kfpos_comm_wait(None, None) == 1
     assert lib.kfpos_comm_world(None) == 0 and lib.kfpos_comm_rank(None) == -1
     assert lib.kfpos_allgather_poses(None, None, None, 3, None, None) == 1
+    assert lib.kfpos_comm_set_algorithm(None, 1) == 1 and lib.kfpos_comm_algorithm(None) == -1
     assert lib.kfpos_strerror(6).decode() == "RCCL error"
 
 
