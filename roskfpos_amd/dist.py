@@ -60,6 +60,12 @@ def default_engine(device) -> str:
     return "cabi" if (dist.is_initialized() and dist.get_world_size() > 1) else "torch"
 
 
+def _consensus_device(device):
+    """where the small tensors live on which the ranks agree (all-reduce): the device for RCCL, the host for gloo"""
+    import torch.distributed as dist
+    return "cpu" if dist.get_backend() == "gloo" else device
+
+
 def make_pose_gather(t_local: int, device, rows: int = 3, sizes=None, engine: str = None):
     """PoseGather with the engine default_engine() picks -- and, when that is the C ABI, a safety net for its first
     contact with a machine: the communicator is created and checked with one predictable gather; if ANY rank fails
@@ -80,7 +86,7 @@ def make_pose_gather(t_local: int, device, rows: int = 3, sizes=None, engine: st
             why = "the check gather returned something else than the pattern sent"
     except Exception as e:  # noqa: BLE001 -- whatever went wrong, the other ranks have to hear about it
         why = f"{type(e).__name__}: {e}"
-    flag = torch.tensor([0 if why else 1], dtype=torch.int32, device=device)
+    flag = torch.tensor([0 if why else 1], dtype=torch.int32, device=_consensus_device(device))
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if int(flag[0]) == 1:
         g.fallback_reason = None
@@ -125,7 +131,7 @@ def _pick_algorithm(g, device, reps: int = 6):
                 us = (time.perf_counter() - t0) * 1e6 / reps
         except Exception:  # noqa: BLE001
             ok = 0
-        v = torch.tensor([float(ok), -us if ok else float("-inf")], dtype=torch.float64, device=device)
+        v = torch.tensor([float(ok), -us if ok else float("-inf")], dtype=torch.float64, device=_consensus_device(device))
         dist.all_reduce(v, op=dist.ReduceOp.MIN)   # ok on every rank; the slowest rank's time
         out[name] = {"ok": bool(v[0] == 1.0), "us_per_gather": (-float(v[1])) if v[0] == 1.0 else None}
     good = [n for n in out if out[n]["ok"]]

@@ -156,3 +156,31 @@ def test_cpp_node_shards_without_python(tmp_path):
     assert res.returncode == 0, res.stdout + res.stderr
     d = json.loads(res.stdout.strip().splitlines()[-1])
     assert d["devices"] == 1 and d["mismatches"] == 0 and d["rccl_version"] >= 20000
+
+
+def test_algorithm_calibration_runs_both_exchanges_and_picks_one():
+    """dist._pick_algorithm -- what bench.py runs before its timed region when every rank has a GPU -- in a process group
+    of one: both ways of moving the blocks are checked with the predictable pattern, timed, and one stays selected."""
+    if not has_gpu():
+        pytest.skip("no GPU")
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    from roskfpos_amd import capi
+    from roskfpos_amd.dist import PoseGather, _pick_algorithm
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        g = PoseGather(4099, "cuda:0", rows=6, engine="cabi")
+        cal = _pick_algorithm(g, "cuda:0")
+        assert cal["collective"]["ok"] and cal["direct"]["ok"] and cal["picked"] in ("collective", "direct")
+        assert cal["collective"]["us_per_gather"] > 0 and cal["direct"]["us_per_gather"] > 0
+        assert g.comm.algorithm == (capi.GATHER_DIRECT if cal["picked"] == "direct" else capi.GATHER_COLLECTIVE)
+        assert g.self_check()
+        g.close()
+    finally:
+        dist.destroy_process_group()
