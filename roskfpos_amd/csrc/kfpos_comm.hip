@@ -486,6 +486,7 @@ int kfpos_allgather_poses_multi(int32_t n, kfpos_handle *const *handles, kfpos_c
     NCCLCHK(rccl().GroupStart());
     ncclResult_t first = ncclSuccess;
     for (int i = 0; i < n; ++i) {
+        KfposDevScope dev(comms[i]->device); /* (the copy of a rank's own block is enqueued by the HIP runtime, not by RCCL) */
         const ncclResult_t r = exchange(plans[i], true);
         if (r != ncclSuccess && first == ncclSuccess) first = r;
     }
