@@ -1237,7 +1237,8 @@ int kfpos_set_state(kfpos_handle *h, const double *x, const double *P, const uin
                     if (h->rsz == 6) { /* round to nearest even on the upper 48 bits, as the kernels do (round48) */
                         uint64_t u;
                         std::memcpy(&u, &v, 8);
-                        u = (u + 0x7FFFull + ((u >> 16) & 1ull)) & ~0xFFFFull;
+                        u = (v != v) ? (u | 0x0008000000000000ull) & ~0xFFFFull
+                                     : (u + 0x7FFFull + ((u >> 16) & 1ull)) & ~0xFFFFull; /* a NaN stays a (quiet) NaN */
                         ((uint32_t *)buf.data())[k] = (uint32_t)(u >> 32);
                         ((uint16_t *)(buf.data() + (size_t)h->psz * T * 4))[k] = (uint16_t)(u >> 16);
                     } else if (h->rsz == 4) ((float *)buf.data())[k] = (float)v;

@@ -155,8 +155,9 @@ constexpr bool cov_is_rounded() { return !std::is_same<REAL, double>::value; }
 __device__ inline double round48(double v) {
     unsigned long long u = (unsigned long long)__double_as_longlong(v);
     u = (u + 0x7FFFull + ((u >> 16) & 1ull)) & ~0xFFFFull;
-    /* (a NaN keeps its quiet bit, which sits in the upper 48: it stays a NaN; +-inf stays +-inf) */
-    return __longlong_as_double((long long)u);
+    /* +-inf stays +-inf; a quiet NaN keeps its quiet bit (it sits in the upper 48); a signalling NaN whose payload is
+     * all in the low 16 bits would round to infinity: any NaN stays a NaN */
+    return v != v ? v : __longlong_as_double((long long)u);
 }
 /* what the storage type keeps of a value: applied between the epochs of a multi-epoch launch, so that it computes what
  * as many single-epoch launches would */
@@ -179,7 +180,8 @@ __device__ inline double ldcov(const void *p, size_t row, size_t rows, size_t T,
 template <typename REAL>
 __device__ inline void stcov(void *p, size_t row, size_t rows, size_t T, uint32_t t, double v) {
     if constexpr (std::is_same<REAL, p48>::value) {
-        const unsigned long long u = (unsigned long long)__double_as_longlong(round48(v));
+        unsigned long long u = (unsigned long long)__double_as_longlong(round48(v));
+        u |= (v != v) ? 0x0008000000000000ull : 0ull; /* a NaN is stored quiet: its upper 48 bits say NaN by themselves */
         (((uint32_t *)p) + row * T)[t] = (uint32_t)(u >> 32);
         (((uint16_t *)(((uint32_t *)p) + rows * T)) + row * T)[t] = (uint16_t)(u >> 16);
     } else {
