@@ -220,3 +220,61 @@ def topn_keep(anchors, ranges, err_est, seed, top_n):
     keep = np.zeros(len(ranges), dtype=np.int32)
     lib().kfo_topn_keep(len(ranges), _f64(anchors), _f64(ranges), _f64(err_est), _f64(seed), top_n, keep)
     return keep
+
+
+class ExtendedOracleBank:
+    """The same restatement evaluated with 64 mantissa bits (oracle/kfpos_oracle_ext.cpp): the 6- and 9-state filters,
+    shared dt, doubles at the boundary. Same calls as OracleBank for what a trace replay needs."""
+
+    _lib = None
+
+    @classmethod
+    def lib(cls):
+        if cls._lib is None:
+            so = os.path.join(_DIR, "libkfpos_oracle_ext.so")
+            src = os.path.join(_DIR, "kfpos_oracle_ext.cpp")
+            if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src),
+                                                                   os.path.getmtime(os.path.join(_DIR, "kfpos_oracle.cpp"))):
+                subprocess.check_call(["make", "-s", "-C", _DIR, "libkfpos_oracle_ext.so"])
+            L = C.CDLL(so)
+            L.kfx_create.restype = C.c_void_p
+            L.kfx_create.argtypes = [C.c_int, C.c_int, C.c_int, _dp, C.c_double, C.c_double, C.c_int, C.c_double, C.c_int,
+                                     C.c_int, C.c_void_p]
+            L.kfx_destroy.argtypes = [C.c_void_p]
+            L.kfx_step_toa.argtypes = [C.c_void_p, C.c_int, C.c_int, _ip, _dp, C.c_double, C.c_void_p, C.c_int]
+            L.kfx_step_imu.argtypes = [C.c_void_p, C.c_int, _dp, _dp, C.c_double, C.c_void_p, C.c_int]
+            L.kfx_get_state.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
+            cls._lib = L
+        return cls._lib
+
+    def __init__(self, model, n_tags, anchors, accel_noise=0.5, jolt=0.5, ignore_worst=False, cost_threshold=0.5,
+                 top_n=0, init_pos=None, n_threads=1):
+        assert model in (MODEL_TOA, MODEL_TOA_IMU)
+        self.T, self.A, self.n, self.n_threads = n_tags, len(anchors), 9 if model == MODEL_TOA_IMU else 6, n_threads
+        ip = None if init_pos is None else _f64(init_pos)
+        self._h = self.lib().kfx_create(model, n_tags, self.A, _f64(anchors), accel_noise, jolt, int(ignore_worst),
+                                        cost_threshold, top_n, int(ip is not None), None if ip is None else ip.ctypes.data)
+
+    def mantissa_bits(self):
+        return self.lib().kfx_mantissa_bits()
+
+    def step_toa(self, range_mm, err_est, dt):
+        st = np.zeros(self.T, dtype=np.uint32)
+        self.lib().kfx_step_toa(self._h, self.T, self.A, np.ascontiguousarray(range_mm, dtype=np.int32), _f64(err_est),
+                                float(dt), st.ctypes.data, self.n_threads)
+        return st
+
+    def step_imu(self, accel, cov, dt):
+        st = np.zeros(self.T, dtype=np.uint32)
+        self.lib().kfx_step_imu(self._h, self.T, _f64(accel), _f64(cov), float(dt), st.ctypes.data, self.n_threads)
+        return st
+
+    def get_state(self):
+        x, P = np.zeros((self.T, self.n)), np.zeros((self.T, self.n, self.n))
+        self.lib().kfx_get_state(self._h, self.T, x, P)
+        return x, P
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self.lib().kfx_destroy(self._h)
+            self._h = None
