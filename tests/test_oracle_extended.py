@@ -61,3 +61,30 @@ def test_double_oracle_vs_extended_precision_on_the_parity_cases(name):
     c = CASE_BY_NAME[name]
     worst, rms, flips = _replay(c, 24, 40, False)
     assert worst <= 1e-9 and flips <= 0.002, (name, worst, rms, flips)
+
+
+@pytest.mark.parametrize("model", [0, 1])
+def test_kernel_body_is_as_close_to_the_extended_evaluation_as_the_oracle_is(model):
+    """The restructured arithmetic of the HIP kernels (host build, tests/emu) against the 64-bit-mantissa evaluation, next
+    to the dense double oracle against it, on the bench workload in small: the kernels' algebra (Woodbury, information
+    form, closed-form cost, Newton reciprocals) is a double-precision evaluation of the same quality as the dense one."""
+    from test_random_traces import _Emu
+    T, S = 256, 100
+    w = Workload(T, 8)
+    init = w.init_positions()
+    ext = oracle_py.ExtendedOracleBank(model, T, w.anchors, init_pos=init, n_threads=4)
+    dbl = oracle_py.OracleBank(model, T, w.anchors, init_pos=init, n_threads=4)
+    emu = _Emu(model, T, w.anchors, init, False, 0)
+    err, cov = w.err_est(), w.accel_cov()
+    gap_dbl = gap_emu = 0.0
+    for s in range(S):
+        r, dt, a = w.ranges_mm(s), w.dt_of(s), w.accel(s)
+        for f in (ext, dbl, emu):
+            if model == 1:
+                f.step_imu(a, cov, 0.0)
+            f.step_toa(r, err, dt)
+        xe = ext.get_state()[0][:, :3]
+        gap_dbl = max(gap_dbl, float(np.abs(dbl.get_state()[0][:, :3] - xe).max()))
+        gap_emu = max(gap_emu, float(np.abs(emu.state()[0][:, :3] - xe).max()))
+    # measured: 6-state 5.3e-15 (oracle) / 5.3e-15 (kernel body); 9-state 7.5e-12 / 5.9e-12
+    assert gap_emu <= 10.0 * max(gap_dbl, 1e-14), (gap_dbl, gap_emu)
