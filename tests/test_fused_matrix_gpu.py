@@ -97,3 +97,36 @@ def test_fused_launch_equals_single_epoch_launches(kind, storage, A, opts, monke
             assert np.array_equal(got[5], ref[5], equal_nan=True), (k, "latch")
         assert np.array_equal(got[0], results[0][0], equal_nan=True), (k, "trajectory")
     assert np.isfinite(results[0][2]).mean() > 0.95
+
+
+@pytest.mark.parametrize("storage,A", [(0, 8), (2, 8), (3, 12)])
+def test_trace_replay_with_a_sensor_covariance_per_epoch(storage, A):
+    """kfpos_run_trace_dev with stride_cov != 0 -- an accelerometer covariance that changes from epoch to epoch -- runs one
+    epoch per launch (the kernels whiten the covariance once per launch) and must equal the single-epoch entry point."""
+    if not has_gpu():
+        pytest.skip("no GPU")
+    import torch
+    from roskfpos_amd import capi
+    T, S = 500, 6
+    w = Workload(T, A)
+    real = np.float64 if storage == capi.STORE_F64 else np.float32
+    dev = "cuda:0"
+    rt = torch.from_numpy(np.ascontiguousarray(np.stack([w.ranges_mm(s) for s in range(S)]).transpose(0, 2, 1))).to(dev)
+    et = torch.from_numpy(np.ascontiguousarray(w.err_est(real).T)).to(dev)
+    at = torch.from_numpy(np.ascontiguousarray(np.stack([w.accel(s, real) for s in range(S)]).transpose(0, 2, 1))).to(dev)
+    covs = np.stack([w.accel_cov(real) * real(1.0 + 0.3 * s) for s in range(S)])          # [S][T][9]
+    ct = torch.from_numpy(np.ascontiguousarray(covs.transpose(0, 2, 1))).to(dev)            # [S][9][T]
+    dts = np.array([w.dt_of(s) for s in range(S)])
+    stream = torch.cuda.current_stream().cuda_stream
+    a = capi.KfposBank(1, T, w.anchors, storage=storage, init_pos=w.init_positions())
+    b = capi.KfposBank(1, T, w.anchors, storage=storage, init_pos=w.init_positions())
+    a.run_trace_dev(S, rt, A * T, et, 0, dts, accel=at, stride_accel=3 * T, cov=ct, stride_cov=9 * T, stream=stream)
+    for s in range(S):
+        b.step_toa_imu_dev(rt[s], et, at[s], ct[s], dts[s], stream=stream)
+    torch.cuda.synchronize()
+    xa, Pa, fa = a.get_state()
+    xb, Pb, fb = b.get_state()
+    assert np.array_equal(xa, xb) and np.array_equal(Pa, Pb) and np.array_equal(fa, fb)
+    assert np.array_equal(a.get_latch(), b.get_latch())
+    a.close()
+    b.close()
