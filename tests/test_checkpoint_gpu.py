@@ -9,26 +9,30 @@ from roskfpos_amd.synth import Workload
 pytestmark = pytest.mark.gpu
 
 
-def test_nine_state_checkpoint_carries_the_latched_imu_sample():
+@pytest.mark.parametrize("storage", [0, 1, 3])
+def test_nine_state_checkpoint_carries_the_latched_imu_sample(storage):
+    """(every storage mode: what get_state hands out is what the kernels keep -- 24 or 48 bits of each covariance entry
+    in the compact modes -- so a restored bank continues bit for bit there too)"""
     from roskfpos_amd import capi
     T, S = 100, 30
     w = Workload(T, 8)
-    cov = w.accel_cov()
+    real = np.float64 if storage == 0 else np.float32
+    cov = w.accel_cov(real)
     cov[:, 1] = cov[:, 3] = 0.002  # a full covariance: all six stored entries matter
 
     def epoch(b, s):
         if s % 3 == 0:
-            return b.step_toa_imu(w.ranges_mm(s), w.err_est(), w.accel(s), cov, w.dt_of(s))
-        return b.step_toa(w.ranges_mm(s), w.err_est(), w.dt_of(s))  # re-fuses the latched sample
+            return b.step_toa_imu(w.ranges_mm(s), w.err_est(real), w.accel(s, real), cov, w.dt_of(s))
+        return b.step_toa(w.ranges_mm(s), w.err_est(real), w.dt_of(s))  # re-fuses the latched sample
 
-    a = capi.KfposBank(capi.MODEL_TOA_IMU, T, w.anchors, init_pos=w.init_positions())
+    a = capi.KfposBank(capi.MODEL_TOA_IMU, T, w.anchors, storage=storage, init_pos=w.init_positions())
     for s in range(S):
         epoch(a, s)
     x, P, fl = a.get_state()
     latch = a.get_latch()
     assert latch.shape == (T, 12) and np.all(fl & 2)
-    np.testing.assert_array_equal(latch[:, 3:].reshape(T, 3, 3), cov.reshape(T, 3, 3))
-    b = capi.KfposBank(capi.MODEL_TOA_IMU, T, w.anchors, init_pos=w.init_positions())
+    np.testing.assert_array_equal(latch[:, 3:].reshape(T, 3, 3), cov.reshape(T, 3, 3).astype(np.float64))
+    b = capi.KfposBank(capi.MODEL_TOA_IMU, T, w.anchors, storage=storage, init_pos=w.init_positions())
     b.set_state(x, P, fl)
     b.set_latch(latch)
     for s in range(S, S + 10):
