@@ -476,7 +476,8 @@ def run(args, cfg, torch, dist, rank, local_rank, world, backend, device, n_dev,
         ms = sorted(r[0] * 1e3 / K for r in runs)
         gather_txt = "none (single GPU)"
         if world > 1:
-            how = {"cabi": "kfpos_allgather_poses (the library's RCCL communicator behind the C ABI: ncclAllGather)",
+            how = {"cabi": "kfpos_allgather_poses (the library's RCCL communicator behind the C ABI: ncclAllGather or "
+                           "grouped ncclSend / ncclRecv, whichever pose_gather_algorithms measured faster)",
                    "torch": ("torch.distributed all_gather_into_tensor over " +
                              ("rccl" if backend == "nccl" else
                               backend + (" on CPU tensors (dry run)" if dry else " (rehearsal: ranks share a card)")))}
@@ -517,6 +518,8 @@ def run(args, cfg, torch, dist, rank, local_rank, world, backend, device, n_dev,
             out["config"]["pose_gather_fallback"] = fallbacks[0]
         if calibrations:  # RCCL's all-gather against every rank sending straight to every other one, timed on this machine
             out["config"]["pose_gather_algorithms"] = calibrations
+        if "cabi" in engines:  # which librccl the communicator runs on (the tests' stand-in transport reports 99999)
+            out["config"]["rccl_version"] = capi.load().kfpos_comm_backend_version()
         if world > 1 and n_dev and world > n_dev:
             out["config"]["note"] = (f"{world} ranks on {n_dev} device(s): a rehearsal of the N > 1 code path, not a "
                                      "scaling measurement")

@@ -203,7 +203,7 @@ class PoseGather:
             raise ValueError("the C-ABI gather shards by kfpos_shard_range; these sizes are something else")
         uid = [capi.comm_unique_id() if self.rank == 0 else None]
         if self.world > 1:  # ship rank 0's ncclUniqueId over the process group that is already up
-            dist.broadcast_object_list(uid, src=0, device=dev)
+            dist.broadcast_object_list(uid, src=0, device=_consensus_device(dev))
         self.comm = capi.KfposComm(self.world, self.rank, uid[0], device=index)
         lo, hi = self.comm.set_total(self.total)
         assert hi - lo == self.t_local and (lo, hi) == shard_range(self.total, self.world, self.rank)

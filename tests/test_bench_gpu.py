@@ -15,9 +15,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BENCH = os.path.join(ROOT, "bench.py")
 
 
-def _run(args, timeout=600):
+def _run(args, timeout=600, **extra_env):
     env = {k: v for k, v in os.environ.items()
            if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE")}
+    env.update(extra_env)
     res = subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, env=env, timeout=timeout)
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [l for l in res.stdout.splitlines() if l.strip()]
@@ -50,3 +51,26 @@ def test_plain_single_gpu_command_reduced_size():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == cb["host_cores"] >= 1 and cb["value"] > 0
     assert d["rms_pos_err_vs_cpu_ref_m"] <= 1e-6
+
+
+def test_two_rank_command_with_the_c_abi_gather():
+    """the branch an 8-GPU node takes -- make_pose_gather's "cabi" engine: communicator, self-check, calibration of the two
+    exchange algorithms, kfpos_allgather_poses per launch -- driven by bench.py itself at two ranks. On a one-GPU box the
+    transport underneath is the tests' stand-in for librccl (tests/fake_rccl; RCCL refuses two ranks on one device)."""
+    if not has_gpu():
+        pytest.skip("no GPU")
+    import torch
+    extra = {}
+    if torch.cuda.device_count() < 2:
+        from test_comm_world_gpu import FAKE_VERSION, _fake
+        extra = dict(KFPOS_RCCL_PATH=_fake(), KFPOS_GATHER_ENGINE="cabi")
+    d = _run(["--gpus", "2", "--config", "c4", "--total-tags", "120001", "--steps", "20", "--warmup", "5",
+              "--gather", "epoch", "--no-cpu-baseline"], **extra)
+    c = d["config"]
+    assert d["n_gpus"] == 2 and c["total_tags"] == 120001 and d["state_finite"] and d["trajectory_matches_state"]
+    assert "pose_gather_fallback" not in c, c.get("pose_gather_fallback")
+    assert "kfpos_allgather_poses" in c["pose_gather"] and "torch.distributed" not in c["pose_gather"]
+    cal = c["pose_gather_algorithms"]
+    assert cal and all(v["collective"]["ok"] and v["direct"]["ok"] for v in cal.values())
+    if extra:
+        assert c["rccl_version"] == FAKE_VERSION

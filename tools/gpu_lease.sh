@@ -3,6 +3,7 @@
 # Output goes to gpurun_out/TAG/ (scratch); copy what should be judged into profiles/ (profiles/README.md).
 #
 #   tests                      the GPU test-suite
+#   one PYTEST_ARGS...         part of it (e.g. tests/test_comm_world_gpu.py -x)
 #   final                      end-of-round validation: suite, smoke(), the driver's bench command, the default bench, the
 #                              plain two-rank command (bench.py spawns its ranks; gloo when they share a card), c4
 #   kbench CONFIGS [STEPS]     tools/kbench.py step-kernel timings (CONFIGS: comma list, e.g. c2,c3,c5)
@@ -23,6 +24,8 @@ kbench() { ( cd $R && timeout -k 10 300 python3 tools/kbench.py --steps ${2:-50}
 case $CMD in
 tests)
   cd $R && timeout -k 10 1100 python3 -m pytest tests -m gpu -q > $OUT/tests.log 2>&1; echo rc=$? >> $OUT/tests.log; tail -5 $OUT/tests.log ;;
+one)
+  cd $R && timeout -k 10 900 python3 -m pytest "$@" -m gpu -q > $OUT/one.log 2>&1; echo rc=$? >> $OUT/one.log; tail -40 $OUT/one.log ;;
 final)
   cd $R
   timeout -k 10 1000 python3 -m pytest tests -m gpu -x -q > $OUT/tests.log 2>&1; echo rc=$? >> $OUT/tests.log; tail -3 $OUT/tests.log

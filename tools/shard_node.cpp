@@ -4,7 +4,9 @@
 // INTEGRATION.md section 3 describes; tests/test_comm_gpu.py builds and runs it on the one device a GPU box has.
 //
 //   hipcc -O2 -std=c++17 -I include -o shard_node tools/shard_node.cpp -L roskfpos_amd/csrc -lkfpos_hip -Wl,-rpath,$PWD/roskfpos_amd/csrc
-//   ./shard_node N_DEVICES TOTAL_TAGS EPOCHS        -> one JSON line; exit status 0 iff every check passed
+//   ./shard_node N_DEVICES TOTAL_TAGS EPOCHS [DEVICES]   -> one JSON line; exit status 0 iff every check passed
+//   DEVICES: comma-separated HIP device per shard (default 0,1,..,N-1). RCCL wants them distinct; the tests' stand-in
+//   transport (tests/fake_rccl) accepts "0,0,0,0" and so runs the 4-shard node on the one card of a GPU box.
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -51,9 +53,18 @@ int main(int argc, char **argv) {
     const int epochs = argc > 3 ? std::atoi(argv[3]) : 20;
     const int A = 8;
     if (n_dev < 1 || total < n_dev) return 2;
+    std::vector<int32_t> dev(n_dev);
+    for (int d = 0; d < n_dev; ++d) dev[d] = d;
+    if (argc > 4) {
+        const char *p = argv[4];
+        for (int d = 0; d < n_dev; ++d) {
+            dev[d] = (int32_t)std::strtol(p, (char **)&p, 10);
+            if (*p == ',') ++p;
+        }
+    }
 
     std::vector<kfpos_comm *> comms(n_dev, nullptr);
-    CHECK(kfpos_comm_create_all(n_dev, nullptr, comms.data())); // devices 0..n_dev-1, one RCCL clique
+    CHECK(kfpos_comm_create_all(n_dev, dev.data(), comms.data())); // one RCCL clique over these devices
     std::vector<kfpos_handle *> h(n_dev, nullptr);
     std::vector<int64_t> lo(n_dev), hi(n_dev);
     std::vector<double *> pos_all(n_dev, nullptr); // [3][total] on every device: the poses of ALL tags
@@ -66,13 +77,13 @@ int main(int argc, char **argv) {
         c.storage = KFPOS_STORE_F64;
         c.accel_noise = 0.5;
         c.use_init_pos = 1;
-        c.device = d;
+        c.device = dev[d];
         CHECK(kfpos_create(&c, &h[d]));
         CHECK(kfpos_set_anchors(h[d], &ANCHORS[0][0], nullptr, A));
         std::vector<double> init((size_t)c.n_tags * 3);
         for (int64_t t = lo[d]; t < hi[d]; ++t) tag_position(t, 0.0, &init[(size_t)(t - lo[d]) * 3]);
         CHECK(kfpos_set_init_positions(h[d], init.data()));
-        HIP(hipSetDevice(d));
+        HIP(hipSetDevice(dev[d]));
         HIP(hipMalloc((void **)&pos_all[d], sizeof(double) * 3 * total));
     }
 
@@ -117,7 +128,7 @@ int main(int argc, char **argv) {
     long mismatches = 0;
     double worst_track = 0.0;
     for (int d = 0; d < n_dev; ++d) {
-        HIP(hipSetDevice(d));
+        HIP(hipSetDevice(dev[d]));
         HIP(hipMemcpy(got.data(), pos_all[d], sizeof(double) * 3 * total, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < got.size(); ++i) mismatches += got[i] != want[i];
     }
