@@ -33,6 +33,7 @@ __global__ __launch_bounds__(WAVE) void k_step_toa6_coop(const KArgs a) {
         skipped_lane(a, t, al == 0);
         return;
     }
+    const auto fl0 = a.flags[t]; /* (read in front of the state loads, written back at the end: see k_step_toa6) */
     const bool has_anchor = al < a.A;
     kc::CoopScratch sc;
     sc.bx = s_anchor[3 * al]; sc.by = s_anchor[3 * al + 1]; sc.bz = s_anchor[3 * al + 2];
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(WAVE) void k_step_toa6_coop(const KArgs a) {
         fin &= isfinite(tg.P.a[k]);
     }
     if (!fin) s |= ST_NONFINITE;
-    a.flags[t] |= FL_STARTED;
+    a.flags[t] = fl0 | FL_STARTED;
     if (a.status) a.status[t] = s;
 }
 

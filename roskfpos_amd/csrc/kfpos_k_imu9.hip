@@ -58,8 +58,11 @@ __global__ __launch_bounds__(WAVE) void k_step_imu9(const KArgs a) {
         return;
     }
 
-    /* load order = order of first use (see k_step_toa6): epoch, position, velocity, IMU sample, then the
-     * 45 covariance entries, which are not needed until the ML solve is over */
+    /* load order = order of first use (see k_step_toa6): flags, epoch, position, velocity, IMU sample, then the
+     * 45 covariance entries, which are not needed until the ML solve is over. The flags word goes first: the compiler
+     * parks it in an AGPR straight away, and vmcnt counts loads in order -- as the last load of the first group it
+     * made that move wait for the whole group before the second group (IMU sample, covariance) was even issued */
+    uint32_t fl = a.flags[t32];
     RawEpoch<MREAL, NA> raw;
     RawImu<MREAL> rawi;
     if constexpr (AS > 0) {
@@ -71,7 +74,6 @@ __global__ __launch_bounds__(WAVE) void k_step_imu9(const KArgs a) {
         tg.pos[k] = (a.pos + k * T)[t32];
         tg.vel[k] = (a.vel + k * T)[t32];
     }
-    uint32_t fl = a.flags[t32];
     /* the covariance and B^-1 wait in LDS while the gain iteration runs, the accelerometer whitener for the whole
      * launch: [78][lane], behind the generic kernel's epoch scratch */
     const CovPark9 park{lds + ((AS == 0 && has_ranging) ? 3 * (size_t)a.A * WAVE : 0) + lane, WAVE};

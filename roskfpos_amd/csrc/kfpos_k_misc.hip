@@ -19,6 +19,7 @@ __global__ __launch_bounds__(WAVE) void k_step_ml(const KArgs a) {
         skipped_lane(a, t, true);
         return;
     }
+    const auto fl0 = a.flags[t]; /* (read at the head, written back at the end: see k_step_toa6) */
     /* _previousEstimation: the per-tag seed lives in the velocity slot of the handle, it is never updated */
     double seed[3] = {1.0, 1.0, 4.0};
     if (a.use_init_pos) {
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(WAVE) void k_step_ml(const KArgs a) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) stcov<REAL>(a.P, k, 6, T, t32, cov[k]);
     }
-    a.flags[t] |= FL_STARTED;
+    a.flags[t] = fl0 | FL_STARTED;
     if (a.status) a.status[t] = s;
 }
 

@@ -51,7 +51,7 @@ PLANAR_CFG = dict(use_fixed_height=1, fixed_height=1.0, init_angle=0.3, px4_heig
                   mag_cov=0.01)
 
 
-def run(name, steps, warmup):
+def run(name, steps, warmup, epl=0):
     model, T, A, storage, top_n, iw, nbytes = CONFIGS[name]
     w = Workload(T, A)
     real = np.float64 if storage == capi.STORE_F64 else np.float32
@@ -79,10 +79,14 @@ def run(name, steps, warmup):
         kw = dict(accel=accel[s0], stride_accel=3 * T, cov=cov, stride_cov=0) if model == 1 else {}
         bank.run_trace_dev(n, ranges[s0], A * T, err, 0, dts[s0:s0 + n], status=status, stream=stream, **kw)
 
-    go(0, warmup)
+    def many(s0, n):  # epl epochs per launch (0: all n in one launch)
+        for k in range(s0, s0 + n, epl or n):
+            go(k, min(epl or n, s0 + n - k))
+
+    many(0, warmup)
     torch.cuda.synchronize()
     bank.timing_begin(stream)
-    go(warmup, steps)
+    many(warmup, steps)
     ms = bank.timing_end(stream)
     us = ms * 1e3 / steps
     st = status.cpu().numpy().astype(np.uint32)
@@ -101,7 +105,7 @@ def run(name, steps, warmup):
     truth = w.position(w.time_of(S - 1))
     if model == 3:
         x, truth = x[:, :2], truth[:, :2]
-    out = {"config": name, "tags": T, "anchors": A, "us_per_launch": round(us, 2),
+    out = {"config": name, "tags": T, "anchors": A, "epochs_per_launch": epl or steps, "us_per_launch": round(us, 2),
            "tag_steps_per_s": T / us * 1e6, "get_pose_us": round(pose_us, 2), "algo_GBps": nbytes * T / us / 1e3,
            "hbm_frac": nbytes * T / us / 1e3 / 8000.0,
            "mean_gain_iters": float(((st >> 8) & 0xFF).mean()), "mean_ml_iters": float(((st >> 16) & 0xFF).mean()),
@@ -121,6 +125,9 @@ if __name__ == "__main__":
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--configs", default="c2,toa6_65k,c3,c5")
+    ap.add_argument("--epochs-per-launch", type=int, default=int(os.environ.get("KBENCH_EPL", "0")),
+                    help="0 = all epochs in one launch (default); 1 = what a live caller of kfpos_step_*_dev pays. "
+                         "us_per_launch is per EPOCH either way (HIP events around all launches, gaps included)")
     a = ap.parse_args()
     for n in a.configs.split(","):
-        run(n, a.steps, a.warmup)
+        run(n, a.steps, a.warmup, a.epochs_per_launch)
