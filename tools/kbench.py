@@ -32,6 +32,10 @@ CONFIGS = {
     "c5_p48": (0, 262144, 16, capi.STORE_P48, 2, False, 344),
     "c5": (0, 262144, 16, capi.STORE_F32, 2, False, 344),
     "iw8": (0, 65536, 8, capi.STORE_F64, 0, True, 560),
+    # the reference's default start: no initial position, every tag initialises from its first ML solve and keeps the
+    # non-symmetric covariance that start leaves (KalmanFilterTOA.cpp:90-108) -- full 36-entry layout, 848 B per unit
+    "toa6_65k_mlinit": (0, 65536, 8, capi.STORE_F64, 0, False, 848),
+    "c3_mlinit": (1, 65536, 8, capi.STORE_MIXED, 0, False, 544),
     # small plain 6-state banks: where the 8-lanes-per-tag kernel (k_step_toa6_coop, KFPOS_NO_COOP=1 disables) pays off
     "t1k": (0, 1024, 8, capi.STORE_F64, 0, False, 560),
     "t8k": (0, 8192, 8, capi.STORE_F64, 0, False, 560),
@@ -67,7 +71,8 @@ def run(name, steps, warmup, epl=0):
     cov = torch.from_numpy(np.ascontiguousarray(w.accel_cov(real).T)).to(dev)
     dts = np.array([w.dt_of(s) for s in range(S)])
     bank = capi.KfposBank(model, T, w.anchors, storage=storage, top_n=top_n, ignore_worst=iw,
-                          init_pos=w.init_positions(), planar=PLANAR_CFG if model == 3 else None)
+                          init_pos=None if name.endswith("_mlinit") else w.init_positions(),
+                          planar=PLANAR_CFG if model == 3 else None)
     if name == "planar_sens":  # latch an IMU and a compass sample: ranging epochs carry their rows from now on
         wv, la = w.planar_imu(0)
         bank.step_planar_imu(wv, np.tile(np.eye(3).ravel() * 1e-4, (T, 1)), la, w.accel_cov(), 0.1)
