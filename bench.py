@@ -61,13 +61,15 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # Covariance storage of c3: BASELINE configs[2] says fp32, i.e. compact storage. With a 24-bit covariance
 # (KFPOS_STORE_F32) the 9-state filter sits at 1.6e-6 m RMS from the CPU reference over 100 steps
 # (tests/test_gpu_parity.py), above the 1e-6 m bar; with the covariance kept as the upper 48 bits of the double
-# (KFPOS_STORE_P48: 6 bytes per entry, measurements f32 / int32) it sits at 5e-10 m, and the kernel is as fast as with
-# an 8-byte covariance (same box, alternating: 37.6-37.7 us per epoch against 38.0-38.3,
-# profiles/r03a_kbench_p48_vs_mixed_same_box.jsonl) -- so P48 is what is measured. KFPOS_BENCH_STORAGE=mixed|f64|f32
-# selects the others. roofline.achieved uses SURVEY 8d's 544 B either way (P48 moves 54*6*2 + 112 = 760 B per tag-step
-# when every epoch is its own launch, MIXED 976 B).
+# (KFPOS_STORE_P48: 6 bytes per entry, measurements f32 / int32) it sits at 5e-10 m. P48 is 2-3 % slower than the
+# 8-byte covariance (same box, alternating: 37.8 against 36.6 us per epoch, profiles/r03k_*: 45 entries are rounded to
+# 48 bits after every epoch so that a launch of K epochs keeps the bits of K launches of one), so the headline runs MIXED
+# -- f64 covariance in HBM, f32 / int32 measurements -- and the SAME line carries the P48 run of the same trace as
+# secondary.c3_p48 (throughput and RMS against the CPU reference): configs[2] as BASELINE.json words it.
+# KFPOS_BENCH_STORAGE=p48|f64|f32 makes another mode the headline. roofline.achieved uses SURVEY 8d's 544 B either way
+# (P48 moves 54*6*2 + 112 = 760 B per tag-step when every epoch is its own launch, MIXED 976 B).
 _STORAGES = {"mixed": capi.STORE_MIXED, "f64": capi.STORE_F64, "f32": capi.STORE_F32, "p48": capi.STORE_P48}
-STORAGE_C3_NAME = os.environ.get("KFPOS_BENCH_STORAGE", "p48")
+STORAGE_C3_NAME = os.environ.get("KFPOS_BENCH_STORAGE", "mixed")
 STORAGE_C3 = _STORAGES[STORAGE_C3_NAME]
 _C3_TEXT = {
     "mixed": ("f64 arithmetic; f64 state and covariance, f32/int32 measurements in HBM (KFPOS_STORE_MIXED)",
@@ -422,6 +424,16 @@ def run(args, cfg, torch, dist, rank, local_rank, world, backend, device, n_dev,
                      "what": "the same K epochs with ONE launch" + (" and one pose all-gather" if world > 1 else "") +
                              " per epoch: the cost of a live 20 Hz caller of kfpos_step_*_dev"}
     secondary = None
+    p48_line = None
+    if args.config == "c3" and not args.no_secondary and not dry and cfg["storage"] != capi.STORE_P48:
+        # configs[2] as BASELINE.json words it -- compact (6-byte) covariance storage -- on the same trace, same K epochs
+        ep, kp, lp, _, bp = measure(E, "none", bank=make_bank(storage=capi.STORE_P48))
+        bp.close()
+        p48_line = {"workload": "the headline workload with KFPOS_STORE_P48: covariance kept as the upper 48 bits of the "
+                                "double (6 B per entry), f32 / int32 measurements",
+                    "kernel": "k_step_imu9<p48,float,8,true>", "value": total * K / ep, "unit": "tag-steps/s",
+                    "ms_per_step": ep * 1e3 / K, "kernel_us_per_launch": kp * 1e3 / lp, "launches": lp,
+                    "roofline_frac": 544 * (T * K / lp) / (kp * 1e-3 / lp) / 1e9 / HBM_PEAK_GBS}
     if args.config == "c3" and not args.no_secondary and not dry:
         # the 6-state filter on the same ranging trace (kbench's toa6_65k): the kernel BASELINE's >= 40 % HBM target
         # is reachable for; f64 storage, so its errorEstimations are f64
@@ -525,6 +537,8 @@ def run(args, cfg, torch, dist, rank, local_rank, world, backend, device, n_dev,
                                      "scaling measurement")
         if per_epoch is not None:
             out["per_epoch_launch"] = per_epoch
+        if p48_line is not None:
+            secondary = dict(secondary or {}, c3_p48=p48_line)
         if secondary is not None:
             out["secondary"] = secondary
         if world == 1 and not args.no_cpu_baseline and not dry:
@@ -542,6 +556,10 @@ def run(args, cfg, torch, dist, rank, local_rank, world, backend, device, n_dev,
                                    "one_core_value": v1,
                                    "one_core_sample": f"first 1024 tags x {60 if imu else 200} steps ({secs1:.1f} s)"}
             out["rms_pos_err_vs_cpu_ref_m"] = rms
+            if p48_line is not None:  # the same sample with the 48-bit covariance against the same reference
+                _, _, rms48 = cpu_baseline_and_rms(dict(cfg, storage=capi.STORE_P48), w, min(sample_tags, 4096),
+                                                   sample_steps, cores)
+                out["secondary"]["c3_p48"]["rms_pos_err_vs_cpu_ref_m"] = rms48
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

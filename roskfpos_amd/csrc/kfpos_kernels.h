@@ -159,11 +159,24 @@ __device__ inline double round48(double v) {
      * all in the low 16 bits would round to infinity: any NaN stays a NaN */
     return v != v ? v : __longlong_as_double((long long)u);
 }
+/* The same for a value that stays in registers between two epochs of a launch (45 entries per tag-epoch in the 9-state
+ * kernel), without the NaN test -- which the compiler turns into a compare, an exec-mask round trip and a branch per
+ * entry. It is not needed there: the carry of the rounding reaches the exponent of a NaN only if mantissa bits 16..51 are
+ * ALL ones, and no NaN a 48-bit-covariance kernel can hold looks like that -- the arithmetic units produce the canonical
+ * quiet NaN (mantissa 1000...0) or hand on the payload of an operand, a stored covariance entry and a converted f32
+ * measurement have their low bits clear; the only f64 inputs are dt, the anchors and the noise parameters, and a NaN
+ * there with 36 leading mantissa ones is not something a caller produces by accident. Finite values and infinities round
+ * exactly as in round48, so a multi-epoch launch and as many single-epoch launches keep the same bits. */
+__device__ inline double round48_in_flight(double v) {
+    unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    u = (u + 0x7FFFull + ((u >> 16) & 1ull)) & ~0xFFFFull;
+    return __longlong_as_double((long long)u);
+}
 /* what the storage type keeps of a value: applied between the epochs of a multi-epoch launch, so that it computes what
  * as many single-epoch launches would */
 template <typename REAL>
 __device__ inline double round_cov(double v) {
-    if constexpr (std::is_same<REAL, p48>::value) return round48(v);
+    if constexpr (std::is_same<REAL, p48>::value) return round48_in_flight(v);
     else return (double)(REAL)v;
 }
 template <typename REAL>

@@ -86,7 +86,9 @@ profile)
   done
   cd $R
   KEY=$(python3 -c "import bench; print(bench.CONFIGS['c3']['kernel'])")
-  python3 tools/traffic_summary.py --match k_step_imu9 --key "$KEY" --tags 65536 --run 25 $OUT/fetch_25 $OUT/write_25 --run 5 $OUT/fetch_5 $OUT/write_5 --note "bench.py --no-cpu-baseline --no-per-epoch --repeats 1 --steps 100 --warmup 25 at 25 and 5 epochs per launch ($TAG)" --merge $OUT/traffic_latest.json > /dev/null
+  # the headline kernel as rocprofv3 spells it (the same process also runs the P48 instantiation: secondary.c3_p48)
+  MATCH=$(python3 -c "import bench; k=bench.CONFIGS['c3']['kernel']; print('k_step_imu9<(anonymous namespace)::p48' if 'p48' in k else k.split(',')[0] + ', ' + k.split(',')[1] + ',')")
+  python3 tools/traffic_summary.py --match "$MATCH" --key "$KEY" --tags 65536 --run 25 $OUT/fetch_25 $OUT/write_25 --run 5 $OUT/fetch_5 $OUT/write_5 --note "bench.py --no-cpu-baseline --no-per-epoch --repeats 1 --steps 100 --warmup 25 at 25 and 5 epochs per launch ($TAG)" --merge $OUT/traffic_latest.json > /dev/null
   python3 tools/traffic_summary.py --match k_step_toa6 --key "k_step_toa6<true,double,double,8,0>" --tags 65536 --run 25 $OUT/fetch_25 $OUT/write_25 --run 5 $OUT/fetch_5 $OUT/write_5 --note "the secondary 6-state line of the same runs ($TAG)" --merge $OUT/traffic_latest.json > /dev/null
   head -40 $OUT/traffic_latest.json
   for d in stats_driver stats_default; do f=$(find $OUT/$d -name "*kernel_stats.csv" | head -1); cp $f $OUT/${d}_kernel_stats.csv; head -6 $f | cut -c1-160; done
@@ -95,7 +97,7 @@ import csv, glob, json
 out = {}
 for d in ("stats_driver", "stats_default"):
     f = glob.glob("$OUT/%s/**/*kernel_trace.csv" % d, recursive=True)[0]
-    rows = [r for r in csv.DictReader(open(f)) if "k_step_imu9" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(f)) if "$MATCH" in r["Kernel_Name"]]
     durs = sorted((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows)
     big = [x for x in durs if x > 0.5 * durs[-1]]
     out[d] = {"k_step_imu9_dispatches": len(durs), "full_size_launches": len(big), "mean_us_full_size_launch": sum(big) / len(big),
