@@ -56,7 +56,10 @@ PLANAR_CFG = dict(use_fixed_height=1, fixed_height=1.0, init_angle=0.3, px4_heig
 
 
 def run(name, steps, warmup, epl=0):
-    model, T, A, storage, top_n, iw, nbytes = CONFIGS[name]
+    base, _, st = name.partition("@")  # "toa6_65k@p48": a configuration in another storage mode
+    model, T, A, storage, top_n, iw, nbytes = CONFIGS[base]
+    if st:
+        storage = {"f64": capi.STORE_F64, "mixed": capi.STORE_MIXED, "f32": capi.STORE_F32, "p48": capi.STORE_P48}[st]
     w = Workload(T, A)
     real = np.float64 if storage == capi.STORE_F64 else np.float32
     S = steps + warmup
@@ -71,9 +74,9 @@ def run(name, steps, warmup, epl=0):
     cov = torch.from_numpy(np.ascontiguousarray(w.accel_cov(real).T)).to(dev)
     dts = np.array([w.dt_of(s) for s in range(S)])
     bank = capi.KfposBank(model, T, w.anchors, storage=storage, top_n=top_n, ignore_worst=iw,
-                          init_pos=None if name.endswith("_mlinit") else w.init_positions(),
+                          init_pos=None if base.endswith("_mlinit") else w.init_positions(),
                           planar=PLANAR_CFG if model == 3 else None)
-    if name == "planar_sens":  # latch an IMU and a compass sample: ranging epochs carry their rows from now on
+    if base == "planar_sens":  # latch an IMU and a compass sample: ranging epochs carry their rows from now on
         wv, la = w.planar_imu(0)
         bank.step_planar_imu(wv, np.tile(np.eye(3).ravel() * 1e-4, (T, 1)), la, w.accel_cov(), 0.1)
         bank.step_compass(w.compass(0), 0.0)
