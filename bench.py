@@ -60,16 +60,16 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 #                                                              (6+21)*8*2 + 8*8*2           = 560 B
 # Covariance storage of c3: BASELINE configs[2] says fp32, i.e. compact storage. With a 24-bit covariance
 # (KFPOS_STORE_F32) the 9-state filter sits at 1.6e-6 m RMS from the CPU reference over 100 steps
-# (tests/test_gpu_parity.py), above the 1e-6 m bar; with the covariance kept as the upper 48 bits of the double
-# (KFPOS_STORE_P48: 6 bytes per entry, measurements f32 / int32) it sits at 5e-10 m. P48 is 2-3 % slower than the
-# 8-byte covariance (same box, alternating: 37.8 against 36.6 us per epoch, profiles/r03k_*: 45 entries are rounded to
-# 48 bits after every epoch so that a launch of K epochs keeps the bits of K launches of one), so the headline runs MIXED
-# -- f64 covariance in HBM, f32 / int32 measurements -- and the SAME line carries the P48 run of the same trace as
-# secondary.c3_p48 (throughput and RMS against the CPU reference): configs[2] as BASELINE.json words it.
-# KFPOS_BENCH_STORAGE=p48|f64|f32 makes another mode the headline. roofline.achieved uses SURVEY 8d's 544 B either way
-# (P48 moves 54*6*2 + 112 = 760 B per tag-step when every epoch is its own launch, MIXED 976 B).
+# (tests/test_gpu_parity.py), above the 1e-6 m bar; KFPOS_STORE_P48 keeps every entry in 6 bytes with 40 significant bits
+# (kfpos_p48.h; measurements f32 / int32): 1e-9 m on this trace, 6.6e-8 m RMS over 2 048 tags x 2 000 epochs with no
+# single epoch above 6e-7 m (profiles/r03m_*), and the kernel is as fast as with an 8-byte covariance (same box,
+# alternating: 36.99 against 37.06 us per epoch, profiles/r03m_ab_p48_vs_mixed_same_box.jsonl) -- VERDICT r2's condition
+# for making it the headline. So P48 is what is measured: configs[2] as BASELINE.json words it.
+# KFPOS_BENCH_STORAGE=mixed|f64|f32 selects another mode (the P48 run then rides along as secondary.c3_p48).
+# roofline.achieved uses SURVEY 8d's 544 B either way (P48 moves 54*6*2 + 112 = 760 B per tag-step when every epoch is
+# its own launch, MIXED 976 B).
 _STORAGES = {"mixed": capi.STORE_MIXED, "f64": capi.STORE_F64, "f32": capi.STORE_F32, "p48": capi.STORE_P48}
-STORAGE_C3_NAME = os.environ.get("KFPOS_BENCH_STORAGE", "mixed")
+STORAGE_C3_NAME = os.environ.get("KFPOS_BENCH_STORAGE", "p48")
 STORAGE_C3 = _STORAGES[STORAGE_C3_NAME]
 _C3_TEXT = {
     "mixed": ("f64 arithmetic; f64 state and covariance, f32/int32 measurements in HBM (KFPOS_STORE_MIXED)",
@@ -78,7 +78,7 @@ _C3_TEXT = {
     "f32": ("f64 arithmetic; f32 covariance and measurements in HBM (KFPOS_STORE_F32)",
             "f32 measurements and covariance (KFPOS_STORE_F32: misses the 1e-6 m bar, 1.6e-6 m)"),
     "p48": ("f64 arithmetic; 48-bit covariance, f32/int32 measurements in HBM (KFPOS_STORE_P48)",
-            "f32/int32 measurements, covariance as the upper 48 bits of the double (KFPOS_STORE_P48: 6 B per entry)"),
+            "f32/int32 measurements, covariance in 6 bytes per entry (KFPOS_STORE_P48: 40 significant bits)"),
 }[STORAGE_C3_NAME]
 CONFIGS = {
     "c3": dict(model=capi.MODEL_TOA_IMU, storage=STORAGE_C3, bytes=544, scaling="weak", tags=65536,
@@ -429,8 +429,8 @@ def run(args, cfg, torch, dist, rank, local_rank, world, backend, device, n_dev,
         # configs[2] as BASELINE.json words it -- compact (6-byte) covariance storage -- on the same trace, same K epochs
         ep, kp, lp, _, bp = measure(E, "none", bank=make_bank(storage=capi.STORE_P48))
         bp.close()
-        p48_line = {"workload": "the headline workload with KFPOS_STORE_P48: covariance kept as the upper 48 bits of the "
-                                "double (6 B per entry), f32 / int32 measurements",
+        p48_line = {"workload": "the headline workload with KFPOS_STORE_P48: covariance in 6 bytes per entry (40 "
+                                "significant bits), f32 / int32 measurements",
                     "kernel": "k_step_imu9<p48,float,8,true>", "value": total * K / ep, "unit": "tag-steps/s",
                     "ms_per_step": ep * 1e3 / K, "kernel_us_per_launch": kp * 1e3 / lp, "launches": lp,
                     "roofline_frac": 544 * (T * K / lp) / (kp * 1e-3 / lp) / 1e9 / HBM_PEAK_GBS}

@@ -54,11 +54,11 @@ extern "C" {
 #define KFPOS_STORE_F64   0 /* covariance double, measurements (kfpos_real) double */
 #define KFPOS_STORE_F32   1 /* covariance float,  measurements (kfpos_real) float */
 #define KFPOS_STORE_MIXED 2 /* covariance double, measurements (kfpos_real) float: exact filter state, compact inputs */
-#define KFPOS_STORE_P48   3 /* covariance as the upper 48 bits of the double (6 bytes per entry: 36 mantissa bits, rounded to
-                               nearest even), measurements float: the compact mode that keeps the 9-state filter inside the
-                               1e-6 m bar on the 100-epoch BASELINE trace (5e-10 m; F32's 24 bits give 1.6e-6 m). Over
-                               2 000 epochs: 3.8e-7 m RMS over all tags and epochs, single epochs up to 3e-6 m (MIXED: 8e-11 /
-                               7e-10 m) -- DESIGN.md section 3 */
+#define KFPOS_STORE_P48   3 /* covariance in 6 bytes per entry -- sign, 8 exponent bits (single's range), 39 mantissa bits,
+                               rounded to nearest (roskfpos_amd/csrc/kfpos_p48.h) --, measurements float: the compact mode
+                               that keeps the 9-state filter inside the 1e-6 m bar (1e-9 m on the 100-epoch BASELINE trace;
+                               6.6e-8 m RMS over 2 048 tags x 2 000 epochs, no single epoch above 6e-7 m; F32's 24 bits give
+                               1.6e-6 m after 100 epochs). An infinite entry is stored as NaN. DESIGN.md section 3 */
 
 #define KFPOS_MAX_ANCHORS 64 /* MAX_NUM_ANCS, Posgenerator.h:74 */
 

@@ -39,6 +39,7 @@
 #define KFPOS_HD __host__ __device__
 #include "kfpos_core.h"
 #include "kfpos_internal.h"
+#include "kfpos_p48.h"
 
 namespace kfpos_k {
 
@@ -144,47 +145,26 @@ __device__ inline void strow(void *p, size_t row, size_t T, uint32_t t, double v
 }
 
 /* ---- the covariance in HBM: [entries][tag] of double / float, or KFPOS_STORE_P48 ----
- * P48: the upper 48 bits of the double, rounded to nearest even -- sign, exponent and 36 mantissa bits (1.5e-11
- * relative), 6 bytes per entry. Two planes so that both stay coalesced: [entries][T] uint32 (bits 63..32) followed by
- * [entries][T] uint16 (bits 31..16); a load is two loads and a shift-or, a store an integer add, a mask and two stores.
- * (The 9-state filter amplifies a 24-bit covariance to 1.6e-6 m over 100 epochs of the BASELINE trace, above the 1e-6 m
- * bar; at 36 bits it stays at 5e-10 m: profiles/r02v_covariance_encoding_study.json.) */
+ * P48 (kfpos_p48.h): sign, 8 exponent bits, 39 mantissa bits -- the single that truncates the value plus the next 16
+ * mantissa bits; 9e-13 relative, 6 bytes per entry. Two planes so that both stay coalesced: [entries][T] uint32 followed
+ * by [entries][T] uint16; a load is two loads, a conversion and a shift-or. (The 9-state filter amplifies a 24-bit
+ * covariance to 1.6e-6 m over 100 epochs of the BASELINE trace, above the 1e-6 m bar.) */
 struct p48 {};
 template <typename REAL>
 constexpr bool cov_is_rounded() { return !std::is_same<REAL, double>::value; }
-__device__ inline double round48(double v) {
-    unsigned long long u = (unsigned long long)__double_as_longlong(v);
-    u = (u + 0x7FFFull + ((u >> 16) & 1ull)) & ~0xFFFFull;
-    /* +-inf stays +-inf; a quiet NaN keeps its quiet bit (it sits in the upper 48); a signalling NaN whose payload is
-     * all in the low 16 bits would round to infinity: any NaN stays a NaN */
-    return v != v ? v : __longlong_as_double((long long)u);
-}
-/* The same for a value that stays in registers between two epochs of a launch (45 entries per tag-epoch in the 9-state
- * kernel), without the NaN test -- which the compiler turns into a compare, an exec-mask round trip and a branch per
- * entry. It is not needed there: the carry of the rounding reaches the exponent of a NaN only if mantissa bits 16..51 are
- * ALL ones, and no NaN a 48-bit-covariance kernel can hold looks like that -- the arithmetic units produce the canonical
- * quiet NaN (mantissa 1000...0) or hand on the payload of an operand, a stored covariance entry and a converted f32
- * measurement have their low bits clear; the only f64 inputs are dt, the anchors and the noise parameters, and a NaN
- * there with 36 leading mantissa ones is not something a caller produces by accident. Finite values and infinities round
- * exactly as in round48, so a multi-epoch launch and as many single-epoch launches keep the same bits. */
-__device__ inline double round48_in_flight(double v) {
-    unsigned long long u = (unsigned long long)__double_as_longlong(v);
-    u = (u + 0x7FFFull + ((u >> 16) & 1ull)) & ~0xFFFFull;
-    return __longlong_as_double((long long)u);
-}
 /* what the storage type keeps of a value: applied between the epochs of a multi-epoch launch, so that it computes what
- * as many single-epoch launches would */
+ * as many single-epoch launches would (KFPOS_STORE_P48: kfpos_p48.h -- three fp64 operations per entry) */
 template <typename REAL>
 __device__ inline double round_cov(double v) {
-    if constexpr (std::is_same<REAL, p48>::value) return round48_in_flight(v);
+    if constexpr (std::is_same<REAL, p48>::value) return kfpos_p48_round(v);
     else return (double)(REAL)v;
 }
 template <typename REAL>
 __device__ inline double ldcov(const void *p, size_t row, size_t rows, size_t T, uint32_t t) {
-    if constexpr (std::is_same<REAL, p48>::value) {
+    if constexpr (std::is_same<REAL, p48>::value) { /* two coalesced planes: [rows][T] uint32, then [rows][T] uint16 */
         const uint32_t hi = (((const uint32_t *)p) + row * T)[t];
         const uint32_t lo = (((const uint16_t *)(((const uint32_t *)p) + rows * T)) + row * T)[t];
-        return __longlong_as_double((long long)(((unsigned long long)hi << 32) | ((unsigned long long)lo << 16)));
+        return kfpos_p48_decode(hi, lo);
     } else {
         (void)rows;
         return (double)(((const REAL *)p) + row * T)[t];
@@ -193,10 +173,11 @@ __device__ inline double ldcov(const void *p, size_t row, size_t rows, size_t T,
 template <typename REAL>
 __device__ inline void stcov(void *p, size_t row, size_t rows, size_t T, uint32_t t, double v) {
     if constexpr (std::is_same<REAL, p48>::value) {
-        unsigned long long u = (unsigned long long)__double_as_longlong(round48(v));
-        u |= (v != v) ? 0x0008000000000000ull : 0ull; /* a NaN is stored quiet: its upper 48 bits say NaN by themselves */
-        (((uint32_t *)p) + row * T)[t] = (uint32_t)(u >> 32);
-        (((uint16_t *)(((uint32_t *)p) + rows * T)) + row * T)[t] = (uint16_t)(u >> 16);
+        uint32_t hi;
+        uint16_t lo;
+        kfpos_p48_encode(kfpos_p48_round(v), &hi, &lo);
+        (((uint32_t *)p) + row * T)[t] = hi;
+        (((uint16_t *)(((uint32_t *)p) + rows * T)) + row * T)[t] = lo;
     } else {
         (void)rows;
         (((REAL *)p) + row * T)[t] = (REAL)v;

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../roskfpos_amd/csrc/kfpos_core.h"
+#include "../../roskfpos_amd/csrc/kfpos_p48.h"
 
 using namespace kfpos;
 
@@ -301,12 +302,11 @@ static double enc_f32_bf16(double v) { /* f32 value + bf16 residual */
     std::memcpy(&lo, &u, 4);
     return (double)hi + (double)lo;
 }
-static double enc_f48(double v) { /* the upper 6 bytes of the double: 36 mantissa bits, rounded */
-    uint64_t u;
-    std::memcpy(&u, &v, 8);
-    u = (u + 0x7FFFull + ((u >> 16) & 1ull)) & ~0xFFFFull;
-    std::memcpy(&v, &u, 8);
-    return v;
+static double enc_f48(double v) { /* KFPOS_STORE_P48 as the kernels keep it: through the same codec (kfpos_p48.h) */
+    uint32_t hi;
+    uint16_t lo;
+    kfpos_p48_encode(kfpos_p48_round(v), &hi, &lo);
+    return kfpos_p48_decode(hi, lo);
 }
 
 /* Emulate KFPOS_STORE_F32: what the step kernels keep in HBM between epochs is rounded to float

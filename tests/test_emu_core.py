@@ -62,7 +62,7 @@ def test_iteration_counts_are_in_the_surveyed_range():
 
 @pytest.mark.parametrize("model,bar", [(1, 5e-9), (0, 1e-10)])
 def test_p48_covariance_storage_keeps_the_bar_on_the_baseline_trace(model, bar):
-    """KFPOS_STORE_P48 (the covariance kept as the upper 48 bits of the double between epochs) on the BASELINE-style
+    """KFPOS_STORE_P48 (the covariance kept in 6 bytes per entry between epochs: 40 significant bits, kfpos_p48.h) on the BASELINE-style
     trace, kernel body on the host: the 9-state filter, which turns a 24-bit covariance into 1.6e-6 m, stays below
     5e-9 m RMS (tests/cov_encoding_study.py: 5.5e-10 m at 2 048 tags). The GPU legs are in test_gpu_parity.py."""
     import ctypes as C

@@ -113,9 +113,13 @@ def test_p48_storage_on_edge_case_traces(case):
     assert np.abs(Po[ok] - Pg[ok]).max() <= 1e-7 * np.abs(Po[ok]).max()
 
 
+from p48 import p48_round_trip as _p48  # numpy mirror of roskfpos_amd/csrc/kfpos_p48.h
+
+
 def test_p48_state_round_trip_and_fused_launch_equals_single_epochs():
-    """kfpos_set_state / kfpos_get_state round the covariance to 48 bits exactly as the kernels store it, and a fused
-    multi-epoch launch rounds between its epochs like as many single-epoch launches do."""
+    """kfpos_set_state / kfpos_get_state round and encode the covariance exactly as the kernels store it (48 bits: sign,
+    8 exponent bits, 39 mantissa bits), and a fused multi-epoch launch rounds between its epochs like as many single-epoch
+    launches do."""
     import torch
     from roskfpos_amd import capi
     from roskfpos_amd.synth import Workload
@@ -133,28 +137,32 @@ def test_p48_state_round_trip_and_fused_launch_equals_single_epochs():
     x2, P2, _ = fused.get_state()
     assert np.array_equal(x1, x2) and np.array_equal(P1, P2)
     bits = P1.view(np.uint64)
-    assert np.all((bits & np.uint64(0xFFFF)) == 0) and np.any(bits & np.uint64(0xFFFF0000))   # 48 bits, and they are used
-    # round trip through the host encoders
+    assert np.all((bits & np.uint64(0x1FFF)) == 0) and np.any(bits & np.uint64(0x1FFFE000))   # 40 significant bits, all used
+    assert np.array_equal(_p48(P1), P1)                                  # what the kernels keep is on the grid of the codec
+    # round trip through the host encoders (roskfpos_amd/csrc/kfpos_p48.h, mirrored in numpy by _p48 above)
     rng = np.random.default_rng(3)
     P = rng.normal(size=(T, 9, 9)) * 10.0 ** rng.integers(-8, 3, size=(T, 1, 1))
     P = P + P.transpose(0, 2, 1)
-    u = P.view(np.uint64)
-    expect = ((u + np.uint64(0x7FFF) + ((u >> np.uint64(16)) & np.uint64(1))) & ~np.uint64(0xFFFF)).view(np.float64)
-    # non-finite entries survive as what they are: infinities, a quiet NaN, and a signalling NaN whose payload sits in
-    # the 16 bits that are dropped (rounding it like a number would make it an infinity)
-    P[0, 0, 0], P[1, 2, 2], P[2, 3, 3] = np.inf, -np.inf, np.nan
-    P.view(np.uint64)[3, 4, 4] = np.uint64(0x7FF0000000000001)
+    # special values: a NaN stays a NaN, an infinity becomes one (inf - inf inside the rounding: an overflowed covariance
+    # entry is not a number either way), magnitudes below single's normal range are stored as signed zero, an exact power
+    # of two and a value one step of the 40-bit grid below it keep their bits
+    P[0, 0, 0], P[1, 2, 2], P[2, 3, 3], P[3, 4, 4] = np.inf, -np.inf, np.nan, -1e-39
+    P[4, 5, 5], P[5, 6, 6], P[6, 7, 7] = 2.0 ** -20, 2.0 ** -20 * (1 - 2.0 ** -40), 0.0
+    expect = _p48(P)
     one.set_state(x1, P)
     _, Pb, _ = one.get_state()
-    special = np.zeros(P.shape, dtype=bool)
-    special[0, 0, 0] = special[1, 2, 2] = special[2, 3, 3] = special[3, 4, 4] = True
-    assert np.array_equal(Pb[~special], expect[~special])
-    assert Pb[0, 0, 0] == np.inf and Pb[1, 2, 2] == -np.inf and np.isnan(Pb[2, 3, 3]) and np.isnan(Pb[3, 4, 4])
-    assert np.abs(Pb[~special] - P[~special]).max() <= 2.0 ** -37 * np.abs(P[~special]).max() * 1.01
+    nan = np.isnan(expect)
+    assert nan[0, 0, 0] and nan[1, 2, 2] and nan[2, 3, 3] and nan.sum() == 3
+    assert np.array_equal(np.isnan(Pb), nan) and np.array_equal(Pb[~nan], expect[~nan])
+    assert Pb[3, 4, 4] == 0.0 and np.signbit(Pb[3, 4, 4]) and Pb[4, 5, 5] == P[4, 5, 5] and Pb[5, 6, 6] == P[5, 6, 6]
+    fin = ~nan & (np.abs(P) > 1e-30)
+    assert (np.abs(Pb[fin] - P[fin]) / np.abs(P[fin])).max() <= 2.0 ** -40
+    one.set_state(x1, Pb)                                                 # idempotent: values on the grid pass unchanged
+    _, Pc, _ = one.get_state()
+    assert np.array_equal(Pc[~nan], Pb[~nan])
     # ... and through a kernel: getPose reads the stored covariance and reports NaN where it is NaN
     _, cov3, _, _ = one.get_pose(0.0)
     assert np.isnan(cov3[2]).any() and np.isfinite(cov3[5]).all()
-
 
 @pytest.mark.parametrize("name", sorted(CASE_BY_NAME))
 def test_gpu_reproduces_golden_fixture(name):
