@@ -30,7 +30,7 @@ for s in range(S):
 po = orc.positions()
 out = {}
 for name, what in (("f64 (8 bytes)", 0), ("f32 (4 bytes)", 1), ("f32 + bf16 residual (6 bytes)", 4),
-                   ("upper 48 bits of the double (6 bytes)", 8)):
+                   ("KFPOS_STORE_P48: single exponent + 39 mantissa bits (6 bytes; round 2 studied the upper 48 bits of the double here)", 8)):
     f = impls.EmuStaticImpl(case, w, w.init_positions())
     for s in range(S):
         f.fused(w.ranges_mm(s), err, w.accel(s, np.float32).astype(np.float64), cov, w.dt_of(s))
