@@ -32,8 +32,11 @@
 /* v on the grid of 40 significant bits, round to nearest (Veltkamp, s = 53 - 40 = 13) */
 KFPOS_HD inline double kfpos_p48_round(double v) {
     double c = v * 8193.0; /* 2^13 + 1 */
+    /* the product is rounded before it is used: no fma(v, 8193, -v), whatever -ffp-contract and -march say */
 #if defined(__HIP_DEVICE_COMPILE__)
-    asm("" : "+v"(c)); /* the product is rounded before it is used: no fma(v, 8193, -v), whatever -ffp-contract says */
+    asm("" : "+v"(c));
+#elif defined(__GNUC__)
+    __asm__("" : "+m"(c));
 #endif
     const double t = c - v;
     return c - t;
