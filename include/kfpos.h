@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define KFPOS_VERSION 101 /* 0.1.1: kfpos_config.ml_variant, kfpos_comm_* */
+#define KFPOS_VERSION 102 /* 0.1.2: KFPOS_STORE_P48 keeps 40 significant bits (0.1.1: kfpos_config.ml_variant, kfpos_comm_*) */
 
 /* ---- return codes (every entry point returns one; 0 = success) ---- */
 #define KFPOS_OK            0

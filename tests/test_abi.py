@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(capi.LIB_PATH)
     for name in _declared_symbols():
         assert hasattr(lib, name), name
-    assert lib.kfpos_version() == 101
+    assert lib.kfpos_version() == 102
 
 
 def test_no_cpu_fallback_without_gpu():
