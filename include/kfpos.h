@@ -48,9 +48,10 @@ extern "C" {
                                compass samples (kfpos_step_sensor). Configure with kfpos_set_planar() before stepping */
 
 /* ---- storage precision of the covariance and of the measurements in HBM; arithmetic is always f64 ----
- * Positions and velocities are kept as double in both modes, ranges are exact integer mm. F32 rounds the
- * covariance to 24 bits between epochs: <= 1e-6 m RMS on the BASELINE traces (measured 5.6e-7 m), but the
- * 9-state filter amplifies that rounding in degraded epochs (< 4 ranges); F64 is exact. */
+ * Positions and velocities are kept as double in every mode, ranges are exact integer mm. F32 rounds the covariance to
+ * 24 bits between epochs: the 6-state filter stays at 3e-9 m from the CPU reference, the 9-state filter amplifies that
+ * rounding to 1.6e-6 m RMS over 100 epochs of the BASELINE trace -- above the 1e-6 m bar: use P48 or MIXED there.
+ * F64 and MIXED keep the covariance exactly. */
 #define KFPOS_STORE_F64   0 /* covariance double, measurements (kfpos_real) double */
 #define KFPOS_STORE_F32   1 /* covariance float,  measurements (kfpos_real) float */
 #define KFPOS_STORE_MIXED 2 /* covariance double, measurements (kfpos_real) float: exact filter state, compact inputs */
