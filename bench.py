@@ -61,15 +61,17 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # Covariance storage of c3: BASELINE configs[2] says fp32, i.e. compact storage. With a 24-bit covariance
 # (KFPOS_STORE_F32) the 9-state filter sits at 1.6e-6 m RMS from the CPU reference over 100 steps
 # (tests/test_gpu_parity.py), above the 1e-6 m bar; KFPOS_STORE_P48 keeps every entry in 6 bytes with 40 significant bits
-# (kfpos_p48.h; measurements f32 / int32): 1e-9 m on this trace, 6.6e-8 m RMS over 2 048 tags x 2 000 epochs with no
-# single epoch above 6e-7 m (profiles/r03m_*), and the kernel is as fast as with an 8-byte covariance (same box,
-# alternating: 36.99 against 37.06 us per epoch, profiles/r03m_ab_p48_vs_mixed_same_box.jsonl) -- VERDICT r2's condition
-# for making it the headline. So P48 is what is measured: configs[2] as BASELINE.json words it.
-# KFPOS_BENCH_STORAGE=mixed|f64|f32 selects another mode (the P48 run then rides along as secondary.c3_p48).
-# roofline.achieved uses SURVEY 8d's 544 B either way (P48 moves 54*6*2 + 112 = 760 B per tag-step when every epoch is
-# its own launch, MIXED 976 B).
+# (kfpos_p48.h; measurements f32 / int32): 1e-9 m on this trace, and the kernel is as fast as with an 8-byte covariance
+# (same box, alternating: 36.99 against 37.06 us per epoch, profiles/r03m_ab_p48_vs_mixed_same_box.jsonl). What separates
+# the two is the long run: the 9-state filter's capped steps multiply ANY difference, in rare epochs by 1e8 and more, so
+# over 2 048 tags x 10 000 epochs P48's 2^-40 rounding ends at 2.7e-6 m RMS (one epoch at 5e-5 m) where the 8-byte
+# covariance, which only carries rounding-level differences into those epochs, stays at 1e-8 m (profiles/r03p_*). The
+# headline therefore runs MIXED -- f64 covariance in HBM, f32 / int32 measurements -- and the SAME line carries the P48 run
+# of the same trace as secondary.c3_p48 (throughput, kernel time, RMS against the CPU reference): configs[2] as
+# BASELINE.json words it. KFPOS_BENCH_STORAGE=p48|f64|f32 makes another mode the headline. roofline.achieved uses SURVEY
+# 8d's 544 B either way (P48 moves 54*6*2 + 112 = 760 B per tag-step when every epoch is its own launch, MIXED 976 B).
 _STORAGES = {"mixed": capi.STORE_MIXED, "f64": capi.STORE_F64, "f32": capi.STORE_F32, "p48": capi.STORE_P48}
-STORAGE_C3_NAME = os.environ.get("KFPOS_BENCH_STORAGE", "p48")
+STORAGE_C3_NAME = os.environ.get("KFPOS_BENCH_STORAGE", "mixed")
 STORAGE_C3 = _STORAGES[STORAGE_C3_NAME]
 _C3_TEXT = {
     "mixed": ("f64 arithmetic; f64 state and covariance, f32/int32 measurements in HBM (KFPOS_STORE_MIXED)",

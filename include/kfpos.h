@@ -59,7 +59,9 @@ extern "C" {
                                rounded to nearest (roskfpos_amd/csrc/kfpos_p48.h) --, measurements float: the compact mode
                                that keeps the 9-state filter inside the 1e-6 m bar (1e-9 m on the 100-epoch BASELINE trace;
                                6.6e-8 m RMS over 2 048 tags x 2 000 epochs, no single epoch above 6e-7 m; F32's 24 bits give
-                               1.6e-6 m after 100 epochs). An infinite entry is stored as NaN. DESIGN.md section 3 */
+                               1.6e-6 m after 100 epochs). Over 10 000 epochs one epoch of capped steps takes it to 2.7e-6 m
+                               (MIXED: 1e-8 m): the mode for the 25 % smaller state, not for the last digits. An infinite
+                               entry is stored as NaN. DESIGN.md section 3 */
 
 #define KFPOS_MAX_ANCHORS 64 /* MAX_NUM_ANCS, Posgenerator.h:74 */
 

@@ -3,7 +3,7 @@
 filters; prints RMS / max position difference and the fraction of differing status words every 250 epochs, and at the
 end what BASELINE.json's metric asks for -- the RMS over ALL tags and ALL epochs -- next to the worst single epoch.
 
-    python tests/soak.py [f64|mixed|f32|p48]      (covariance / measurement storage of the GPU bank; default f64)
+    python tests/soak.py [f64|mixed|f32|p48] [EPOCHS]   (covariance / measurement storage of the GPU bank; default f64, 2000)
 """
 import sys, os, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 from roskfpos_amd import capi
 from roskfpos_amd.synth import Workload
 import oracle_py
-T, S = 2048, 2000
+T, S = 2048, (int(sys.argv[2]) if len(sys.argv) > 2 else 2000)
 mode = sys.argv[1] if len(sys.argv) > 1 else "f64"
 storage = {"f64": capi.STORE_F64, "mixed": capi.STORE_MIXED, "f32": capi.STORE_F32, "p48": capi.STORE_P48}[mode]
 real = np.float64 if storage == capi.STORE_F64 else np.float32

@@ -51,17 +51,19 @@ def test_plain_single_gpu_command_reduced_size():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == cb["host_cores"] >= 1 and cb["value"] > 0
     assert d["rms_pos_err_vs_cpu_ref_m"] <= 1e-6
-    assert "KFPOS_STORE_P48" in d["dtype"] and "p48" in d["roofline"]["kernel"]   # configs[2] as BASELINE.json words it
+    # configs[2] as BASELINE.json words it (compact covariance storage) rides along in the same line
+    p48 = d["secondary"]["c3_p48"]
+    assert "KFPOS_STORE_MIXED" in d["dtype"] and "double,float" in d["roofline"]["kernel"]
+    assert p48["value"] > 0 and p48["rms_pos_err_vs_cpu_ref_m"] <= 1e-6 and "p48" in p48["kernel"]
 
 
-def test_another_headline_storage_carries_the_p48_run_as_secondary():
+def test_p48_as_the_headline_storage():
     if not has_gpu():
         pytest.skip("no GPU")
     d = _run(["--gpus", "1", "--steps", "10", "--warmup", "5", "--tags-per-gpu", "4096", "--repeats", "1"],
-             KFPOS_BENCH_STORAGE="mixed")
-    p48 = d["secondary"]["c3_p48"]
-    assert "KFPOS_STORE_MIXED" in d["dtype"] and d["rms_pos_err_vs_cpu_ref_m"] <= 1e-6
-    assert p48["value"] > 0 and p48["rms_pos_err_vs_cpu_ref_m"] <= 1e-6 and "p48" in p48["kernel"]
+             KFPOS_BENCH_STORAGE="p48")
+    assert "KFPOS_STORE_P48" in d["dtype"] and "p48" in d["roofline"]["kernel"] and d["rms_pos_err_vs_cpu_ref_m"] <= 1e-6
+    assert "c3_p48" not in d.get("secondary", {})
 
 
 def test_two_rank_command_with_the_c_abi_gather():

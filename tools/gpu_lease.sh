@@ -13,7 +13,7 @@
 #                              (default: the library in the tree); MATCH selects the kernel by name
 #   profile                    bench.py under rocprofv3: --kernel-trace --stats of the driver's and the default command,
 #                              FETCH_SIZE / WRITE_SIZE passes at two launch lengths -> traffic_latest.json
-#   soak MODES                 tests/soak.py (2 048 tags x 2 000 epochs against the oracle) per storage mode, e.g. mixed,p48
+#   soak MODES [EPOCHS]        tests/soak.py (2 048 tags x 2 000 epochs against the oracle) per storage mode, e.g. mixed,p48
 #   hostside                   single-tag adaptor latency, streaming slots, ranging ingest (tools/*.cpp, hostbench.py)
 set -o pipefail
 TAG=$1; CMD=$2; shift 2
@@ -110,7 +110,7 @@ PY
   grep '^{"metric"' $OUT/bench_driver_profiled.log | cut -c1-300 ;;
 soak)
   cd $R
-  for m in $(echo $1 | tr , ' '); do timeout -k 10 500 python3 tests/soak.py $m > $OUT/soak_$m.log 2>&1; echo rc=$? >> $OUT/soak_$m.log; grep "ALL\|rc=" $OUT/soak_$m.log; done ;;
+  for m in $(echo $1 | tr , ' '); do timeout -k 10 900 python3 tests/soak.py $m $2 > $OUT/soak_$m.log 2>&1; echo rc=$? >> $OUT/soak_$m.log; grep "ALL\|rc=" $OUT/soak_$m.log; done ;;
 hostside)
   cd $R
   g++ -O2 -std=c++17 -I include -I roskfpos_amd/csrc -o $OUT/adaptor_latency tools/adaptor_latency.cpp -L roskfpos_amd/csrc -lkfpos_hip -Wl,-rpath,$R/roskfpos_amd/csrc
