@@ -204,7 +204,7 @@ def _unsharded(total, steps):
     return trace["traj"].cpu().numpy()
 
 
-@pytest.mark.parametrize("world,total", [(2, 2 * 30000 + 1), (3, 3 * 20000 + 2)])  # one-tag-per-lane kernels on both sides
+@pytest.mark.parametrize("world,total", [(2, 2 * 30000 + 1), (3, 3 * 20000 + 2), (4, 4 * 15000 + 3)])  # one-tag-per-lane kernels on both sides
 def test_ranks_in_processes_gather_what_one_bank_computes(world, total, tmp_path):
     """Every rank -- not only rank 0 -- ends up with the poses of ALL tags, bit for bit what one unsharded bank computes,
     per epoch, per launch and per trajectory block, with RCCL's all-gather and with the direct exchange."""
